@@ -1,0 +1,76 @@
+// extern "C" surface of libdiffmusic_hip.so (declared in include/diffmusic_hip.h).
+#include "models.h"
+
+#define M_IMPL(m) ((m) ? (m)->impl : nullptr)
+#define ST(s) ((hipStream_t)(s))
+
+extern "C" {
+
+int dmx_abi_version(void) { return DMX_ABI_VERSION; }
+int dmx_act_dtype(void) { return DMX_ACT_DTYPE; }
+
+dmx_model* dmx_hifigan_create(const dmx_hifigan_config* cfg) {
+  if (!cfg || cfg->num_upsamples > DMX_MAX_STAGES || cfg->num_kernels > DMX_MAX_STAGES || cfg->num_dilations > DMX_MAX_STAGES) {
+    dmx_set_error("bad hifigan config");
+    return nullptr;
+  }
+  return new dmx_model{dmx_make_hifigan(cfg)};
+}
+dmx_model* dmx_vae_decoder_create(const dmx_vae_config* cfg) {
+  if (!cfg || cfg->num_blocks > DMX_MAX_STAGES) { dmx_set_error("bad vae config"); return nullptr; }
+  Model* m = dmx_make_vae(cfg);
+  return m ? new dmx_model{m} : nullptr;
+}
+dmx_model* dmx_unet_create(const dmx_unet_config* cfg) {
+  if (!cfg || cfg->num_blocks > DMX_MAX_STAGES) { dmx_set_error("bad unet config"); return nullptr; }
+  Model* m = dmx_make_unet(cfg);
+  return m ? new dmx_model{m} : nullptr;
+}
+void dmx_model_destroy(dmx_model* m) {
+  if (!m) return;
+  delete m->impl;
+  delete m;
+}
+int dmx_model_num_params(const dmx_model* m) { return (int)m->impl->ps.params.size(); }
+const char* dmx_model_param_name(const dmx_model* m, int i) { return m->impl->ps.params[i].name.c_str(); }
+size_t dmx_model_param_numel(const dmx_model* m, int i) { return m->impl->ps.params[i].numel; }
+int dmx_model_param_ndim(const dmx_model* m, int i) { return (int)m->impl->ps.params[i].shape.size(); }
+int dmx_model_param_dim(const dmx_model* m, int i, int d) { return m->impl->ps.params[i].shape[d]; }
+int dmx_model_load_param(dmx_model* m, const char* name, const float* data_host, size_t numel) {
+  if (m->impl->finalized) { dmx_set_error("model already finalized"); return DMX_ERR_STATE; }
+  return m->impl->ps.load(name, data_host, numel);
+}
+int dmx_model_finalize(dmx_model* m, void* stream) {
+  std::string missing;
+  if (!m->impl->ps.all_loaded(&missing)) { dmx_set_error("parameter '%s' was never loaded", missing.c_str()); return DMX_ERR_PARAM; }
+  const int rc = m->impl->finalize(ST(stream));
+  if (rc == DMX_OK) m->impl->finalized = true;
+  return rc;
+}
+
+static int check(dmx_model* m, int kind) {
+  if (!m || !m->impl || m->impl->kind != kind) { dmx_set_error("wrong model handle"); return DMX_ERR_STATE; }
+  if (!m->impl->finalized) { dmx_set_error("model not finalized"); return DMX_ERR_STATE; }
+  return DMX_OK;
+}
+
+int dmx_hifigan_out_len(const dmx_model* m, int frames) { return dmx_hifigan_out_len_impl(m->impl, frames); }
+size_t dmx_hifigan_workspace_bytes(dmx_model* m, int batch, int frames) { return dmx_hifigan_ws_impl(m->impl, batch, frames); }
+int dmx_hifigan_fwd(dmx_model* m, const uint16_t* mel, float* wav, int batch, int frames, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check(m, DMX_MODEL_HIFIGAN);
+  if (rc) return rc;
+  if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
+  return dmx_hifigan_fwd_impl(m->impl, mel, wav, batch, frames, ws, ws_bytes, ST(stream));
+}
+int dmx_hifigan_bwd(dmx_model* m, const float* dwav, uint16_t* dmel, void* stream) {
+  int rc = check(m, DMX_MODEL_HIFIGAN);
+  if (rc) return rc;
+  return dmx_hifigan_bwd_impl(m->impl, dwav, dmel, ST(stream));
+}
+
+int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream) {
+  if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
+  return dmx_gemm_launch(*reinterpret_cast<const GemmDesc*>(desc), ST(stream));
+}
+
+}  // extern "C"

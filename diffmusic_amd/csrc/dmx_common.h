@@ -1,0 +1,116 @@
+// Common device/host helpers for the DiffMusic MI355X (gfx950) hot-path library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// 16-bit activation type: raw bits of fp16 (default) or bf16 (-DDMX_BF16); all activation tensors are
+// channels-last.  fp16 matches the reference's own torch_dtype=float16 (run.py:218) and has 8x less rounding
+// noise than bf16, which matters for the leaky-relu' masks of near-zero units in the guidance gradient.
+typedef uint16_t act_t;
+
+#define DMX_OK 0
+#define DMX_ERR_SHAPE (-1)
+#define DMX_ERR_WORKSPACE (-2)
+#define DMX_ERR_PARAM (-3)
+#define DMX_ERR_STATE (-4)
+#define DMX_ERR_LAUNCH (-5)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#ifdef DMX_BF16
+typedef __bf16 native16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 frag8_t;
+#define DMX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define DMX_ACT_DTYPE 0
+#else
+typedef _Float16 native16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 frag8_t;
+#define DMX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define DMX_ACT_DTYPE 1
+#endif
+
+__device__ __forceinline__ float a2f(act_t v) { return (float)__builtin_bit_cast(native16_t, v); }
+__device__ __forceinline__ act_t f2a(float f) { return __builtin_bit_cast(act_t, (native16_t)f); }
+__device__ __forceinline__ uint32_t pack2a(float lo, float hi) { return (uint32_t)f2a(lo) | ((uint32_t)f2a(hi) << 16); }
+__device__ __forceinline__ float alo(uint32_t u) { return a2f((act_t)(u & 0xffffu)); }
+__device__ __forceinline__ float ahi(uint32_t u) { return a2f((act_t)(u >> 16)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x multiple of 64 (<=1024); `sh` needs 16 floats
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = -3.0e38f;
+  for (int i = 0; i < nw; ++i) r = fmaxf(r, sh[i]);
+  return r;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor.  C[m, n] = sum_k A_gather[m, k] * W[n, k]
+//   rows m enumerate (b, qy, qx) over (B, Hq, Wq); k enumerates (tap, cin) tap-major.
+//   input pixel  : iy = qy*sy + tdy[tap], ix = qx*sx + tdx[tap]  (zero outside [0,Hi)x[0,Wi))
+//   output pixel : oy = qy*osy + ooy,     ox = qx*osx + oox
+// Plain / batched GEMMs use ntaps=1, Hq=1, Wq=M and the z strides.
+#define DMX_MAX_TAPS 16
+enum {
+  EPI_BIAS = 1,        // + bias[n]                     (fp32)
+  EPI_ROWBIAS = 2,     // + rowbias[b, n]               (fp32, ld = N) per batch image
+  EPI_RESID = 4,       // + R[row, n]                   (bf16, same indexing as C, ld = ldr)
+  EPI_ACCUM = 8,       // + previous C[row, n]          (after alpha)
+  EPI_MASK = 16,       // * (X[row, n] > 0 ? 1 : mask_slope)   applied to acc before resid
+  EPI_LRELU2 = 32,     // second output C2 = leaky_relu(v, act_slope)
+  EPI_TANH = 64,       // v = tanh(v)
+  EPI_F32OUT = 128,    // C is float* instead of bf16*
+  EPI_NO_C = 256,      // skip the primary output (only C2)
+  EPI_GELU_GATE = 512  // unused
+};
+
+struct GemmDesc {
+  const act_t* A;
+  const act_t* W;
+  void* C;
+  act_t* C2;
+  const float* bias;
+  const float* rowbias;
+  const act_t* R;
+  const act_t* X;
+  int M, N, K;           // K = ntaps*Ci (un-padded); ldw = W row stride in elements
+  int ldw;
+  int Hi, Wi, Ci, lda;   // input geometry; lda = elements per input pixel
+  int Hq, Wq, sy, sx;
+  int ntaps;
+  int Ho, Wo, ldc, osy, ooy, osx, oox;
+  int ldr, ldx, ldc2;
+  int Z, Zi;             // batch count and inner batch size (z = zo*Zi + zi)
+  long long sAo, sAi, sWo, sWi, sCo, sCi;
+  float alpha, act_slope, mask_slope;
+  int flags;
+  signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
+};
+
+int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);

@@ -1,0 +1,591 @@
+// Pointwise / reduction kernels around the contractions (all HBM-bound): GroupNorm(+SiLU) fwd+bwd,
+// LayerNorm, row softmax fwd+bwd, GEGLU, nearest upsample fwd+bwd, transposes, channel concat and
+// the layout conversions at the stage boundaries.  Activations are channels-last bf16; every
+// thread moves 16 bytes (8 channels) per access and reductions use wave64 shuffles + LDS.
+#include "dmx_common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+  f[0] = alo(u.x); f[1] = ahi(u.x); f[2] = alo(u.y); f[3] = ahi(u.y);
+  f[4] = alo(u.z); f[5] = ahi(u.z); f[6] = alo(u.w); f[7] = ahi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  return make_uint4(pack2a(f[0], f[1]), pack2a(f[2], f[3]), pack2a(f[4], f[5]), pack2a(f[6], f[7]));
+}
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float s = 1.f / (1.f + __expf(-z));
+  return s * (1.f + z * (1.f - s));
+}
+
+// ------------------------------------------------------------------------------ GroupNorm
+// x: (B, P, C).  Block = cpr*rpb threads (cpr = C/8 chunk columns, rpb pixel rows in flight);
+// grid = (nchunk, B).  MODE 0: stats of x.  MODE 1: backward sums of dxhat and dxhat*xhat.
+template <int MODE>
+__global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __restrict__ dy,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  const float* __restrict__ stats, float* __restrict__ partial,
+                                  int P, int C, int G, int rpb, int ppb, int silu) {
+  extern __shared__ float sh[];  // [rpb][C][2]
+  const int cpr = C >> 3;
+  const int col = threadIdx.x % cpr, row = threadIdx.x / cpr;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+  const int c0 = col << 3;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
+  float sc[8], sf[8], mu[8], rs[8];
+  if (MODE == 1) {
+    const int cpg = C / G;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc[i] = scale[(long long)b * C + c0 + i];
+      sf[i] = shift[(long long)b * C + c0 + i];
+      const int g = (c0 + i) / cpg;
+      mu[i] = stats[((long long)b * G + g) * 2];
+      rs[i] = stats[((long long)b * G + g) * 2 + 1];
+    }
+  }
+  const act_t* xb = x + (long long)b * P * C;
+  const act_t* db = MODE == 1 ? dy + (long long)b * P * C : nullptr;
+  for (int p = p0 + row; p < p1; p += rpb) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(xb + (long long)p * C + c0), f);
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s1[i] += f[i]; s2[i] += f[i] * f[i]; }
+    } else {
+      float d[8];
+      unpack8(*reinterpret_cast<const uint4*>(db + (long long)p * C + c0), d);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float z = f[i] * sc[i] + sf[i];
+        const float dz = silu ? d[i] * dsilu_f(z) : d[i];
+        const float dxh = dz * sc[i];              // = dz*gamma*rstd ; divide rstd out in finalize
+        const float xh = (f[i] - mu[i]) * rs[i];
+        s1[i] += dxh; s2[i] += dxh * xh;
+      }
+    }
+  }
+  float* my = sh + ((long long)row * C + c0) * 2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { my[2 * i] = s1[i]; my[2 * i + 1] = s2[i]; }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int r = 0; r < rpb; ++r)
+      for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sh[((long long)r * C + c) * 2]; q += sh[((long long)r * C + c) * 2 + 1]; }
+    float* out = partial + (((long long)b * gridDim.x + blockIdx.x) * G + g) * 2;
+    if (MODE == 0) {
+      const float n = (float)(p1 - p0) * cpg;
+      const float m = n > 0 ? a / n : 0.f;
+      out[0] = m;                       // local mean
+      out[1] = fmaxf(q - a * m, 0.f);   // local M2
+    } else {
+      out[0] = a; out[1] = q;
+    }
+  }
+}
+
+// combine partials -> stats[b,g] = (mean, rstd); scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ stats,
+                                   float* __restrict__ scale, float* __restrict__ shift,
+                                   int P, int C, int G, int nchunk, int ppb, float eps) {
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x, cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      const int cnt = min(P, (k + 1) * ppb) - k * ppb;
+      if (cnt <= 0) break;
+      const float nb = (float)cnt * cpg;
+      const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
+      const float delta = pp[0] - mean, nn = n + nb;
+      mean += delta * nb / nn;
+      m2 += pp[1] + delta * delta * n * nb / nn;
+      n = nn;
+    }
+    const float rstd = rsqrtf(m2 / n + eps);
+    s_mean[g] = mean; s_rstd[g] = rstd;
+    stats[((long long)b * G + g) * 2] = mean;
+    stats[((long long)b * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float a = s_rstd[g] * gamma[c];
+    scale[(long long)b * C + c] = a;
+    shift[(long long)b * C + c] = beta[c] - s_mean[g] * a;
+  }
+}
+
+// y = act(x*scale + shift)
+__global__ void gn_apply_kernel(const act_t* __restrict__ x, const float* __restrict__ scale,
+                                const float* __restrict__ shift, act_t* __restrict__ y,
+                                int P, int C, int rpb, int ppb, int silu) {
+  const int cpr = C >> 3;
+  const int col = threadIdx.x % cpr, row = threadIdx.x / cpr;
+  const int b = blockIdx.y, c0 = col << 3;
+  const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+  float sc[8], sf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { sc[i] = scale[(long long)b * C + c0 + i]; sf[i] = shift[(long long)b * C + c0 + i]; }
+  const long long base = (long long)b * P * C + c0;
+  for (int p = p0 + row; p < p1; p += rpb) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = f[i] * sc[i] + sf[i];
+      f[i] = silu ? silu_f(z) : z;
+    }
+    *reinterpret_cast<uint4*>(y + base + (long long)p * C) = pack8(f);
+  }
+}
+
+// backward finalize: per (b,c) coefficients k0, k1 with dx = scale*dy*act'(z) + k0 + k1*x
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+                                       float* __restrict__ k0, float* __restrict__ k1,
+                                       int P, int C, int G, int nchunk) {
+  __shared__ float s_c1[64], s_c2[64];
+  const int b = blockIdx.x, cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
+      a += pp[0]; q += pp[1];
+    }
+    const float n = (float)P * cpg;
+    s_c1[g] = a / n;   // mean(dz*gamma*rstd)          (rstd already folded in via `scale`)
+    s_c2[g] = q / n;   // mean(dz*gamma*rstd * xhat)
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
+    // dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), with rstd*dxhat == scale*dz
+    // => dx = scale*dz - c1 - c2*rstd*(x-mean)
+    k0[(long long)b * C + c] = -s_c1[g] + s_c2[g] * rstd * mean;
+    k1[(long long)b * C + c] = -s_c2[g] * rstd;
+  }
+}
+
+__global__ void gn_bwd_apply_kernel(const act_t* __restrict__ x, const act_t* __restrict__ dy,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ k0, const float* __restrict__ k1,
+                                    const act_t* __restrict__ add, act_t* __restrict__ dx,
+                                    int P, int C, int rpb, int ppb, int silu) {
+  const int cpr = C >> 3;
+  const int col = threadIdx.x % cpr, row = threadIdx.x / cpr;
+  const int b = blockIdx.y, c0 = col << 3;
+  const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+  float sc[8], sf[8], a0[8], a1[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long o = (long long)b * C + c0 + i;
+    sc[i] = scale[o]; sf[i] = shift[o]; a0[i] = k0[o]; a1[i] = k1[o];
+  }
+  const long long base = (long long)b * P * C + c0;
+  for (int p = p0 + row; p < p1; p += rpb) {
+    float f[8], d[8], r[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), f);
+    unpack8(*reinterpret_cast<const uint4*>(dy + base + (long long)p * C), d);
+    if (add) unpack8(*reinterpret_cast<const uint4*>(add + base + (long long)p * C), r);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = f[i] * sc[i] + sf[i];
+      const float dz = silu ? d[i] * dsilu_f(z) : d[i];
+      float v = sc[i] * dz + a0[i] + a1[i] * f[i];
+      if (add) v += r[i];
+      f[i] = v;
+    }
+    *reinterpret_cast<uint4*>(dx + base + (long long)p * C) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------------------ LayerNorm (rows, C)
+__global__ void layernorm_kernel(const act_t* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, act_t* __restrict__ y, int rows, int C, float eps) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= rows) return;
+  const act_t* xr = x + (long long)wave * C;
+  float s = 0.f, q = 0.f;
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(xr + c), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s += f[i]; q += f[i] * f[i]; }
+  }
+  s = wave_sum(s); q = wave_sum(q);
+  const float mean = s / C, rstd = rsqrtf(fmaxf(q / C - mean * mean, 0.f) + eps);
+  for (int c = lane * 8; c < C; c += 512) {
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(xr + c), f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * gamma[c + i] + beta[c + i];
+    *reinterpret_cast<uint4*>(y + (long long)wave * C + c) = pack8(f);
+  }
+}
+
+// ------------------------------------------------------------------------------ softmax
+// S fp32 (rows, N) ld=lds -> P bf16 (rows, N) ld=ldp; optional additive column bias (mask)
+__global__ void softmax_kernel(const float* __restrict__ S, act_t* __restrict__ P, const float* __restrict__ colbias,
+                               int N, long long lds, long long ldp, int rows_per_bias) {
+  __shared__ float sh[16];
+  const long long row = blockIdx.x;
+  const float* s = S + row * lds;
+  const float* cb = colbias ? colbias + (row / rows_per_bias) * N : nullptr;
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, s[i] + (cb ? cb[i] : 0.f));
+  mx = block_max(mx, sh);
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) sum += __expf(s[i] + (cb ? cb[i] : 0.f) - mx);
+  sum = block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  act_t* p = P + row * ldp;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) p[i] = f2a(__expf(s[i] + (cb ? cb[i] : 0.f) - mx) * inv);
+}
+
+// dS = P * (dP - sum_j dP_j P_j) * scale ; P bf16, dP fp32 -> dS bf16
+__global__ void softmax_bwd_kernel(const act_t* __restrict__ P, const float* __restrict__ dP, act_t* __restrict__ dS,
+                                   int N, long long ld, float scale) {
+  __shared__ float sh[16];
+  const long long row = blockIdx.x;
+  const act_t* p = P + row * ld;
+  const float* d = dP + row * ld;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) acc += a2f(p[i]) * d[i];
+  acc = block_sum(acc, sh);
+  act_t* o = dS + row * ld;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) o[i] = f2a(a2f(p[i]) * (d[i] - acc) * scale);
+}
+
+// ------------------------------------------------------------------------------ GEGLU: (rows, 2I) -> (rows, I)
+__global__ void geglu_kernel(const act_t* __restrict__ x, act_t* __restrict__ y, long long rows, int I) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = I >> 3;
+  if (idx >= rows * cpr) return;
+  const long long r = idx / cpr;
+  const int c = (int)(idx - r * cpr) << 3;
+  float a[8], g[8];
+  unpack8(*reinterpret_cast<const uint4*>(x + r * 2 * I + c), a);
+  unpack8(*reinterpret_cast<const uint4*>(x + r * 2 * I + I + c), g);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] *= 0.5f * g[i] * (1.f + erff(g[i] * 0.70710678118654752f));
+  *reinterpret_cast<uint4*>(y + r * I + c) = pack8(a);
+}
+
+__global__ void silu_kernel(const act_t* __restrict__ x, act_t* __restrict__ y, long long n8) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  float f[8];
+  unpack8(reinterpret_cast<const uint4*>(x)[idx], f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = silu_f(f[i]);
+  reinterpret_cast<uint4*>(y)[idx] = pack8(f);
+}
+
+// ------------------------------------------------------------------------------ nearest upsample (B,Hi,Wi,C)->(B,Ho,Wo,C)
+__global__ void upsample_nearest_kernel(const act_t* __restrict__ x, act_t* __restrict__ y,
+                                        int B, int Hi, int Wi, int Ho, int Wo, int C) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = C >> 3;
+  const long long total = (long long)B * Ho * Wo * cpr;
+  if (idx >= total) return;
+  const int c = (int)(idx % cpr) << 3;
+  long long pix = idx / cpr;
+  const int ox = (int)(pix % Wo); pix /= Wo;
+  const int oy = (int)(pix % Ho); const int b = (int)(pix / Ho);
+  const int iy = min((int)floorf(oy * ((float)Hi / Ho)), Hi - 1), ix = min((int)floorf(ox * ((float)Wi / Wo)), Wi - 1);
+  *reinterpret_cast<uint4*>(y + (((long long)b * Ho + oy) * Wo + ox) * C + c) =
+      *reinterpret_cast<const uint4*>(x + (((long long)b * Hi + iy) * Wi + ix) * C + c);
+}
+// exact x2 backward: dx[iy,ix] = sum of the 2x2 block
+__global__ void upsample2x_bwd_kernel(const act_t* __restrict__ dy, act_t* __restrict__ dx, int B, int Hi, int Wi, int C) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = C >> 3;
+  const long long total = (long long)B * Hi * Wi * cpr;
+  if (idx >= total) return;
+  const int c = (int)(idx % cpr) << 3;
+  long long pix = idx / cpr;
+  const int ix = (int)(pix % Wi); pix /= Wi;
+  const int iy = (int)(pix % Hi); const int b = (int)(pix / Hi);
+  const int Ho = Hi * 2, Wo = Wi * 2;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int dyi = 0; dyi < 2; ++dyi)
+#pragma unroll
+    for (int dxi = 0; dxi < 2; ++dxi) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + (((long long)b * Ho + 2 * iy + dyi) * Wo + 2 * ix + dxi) * C + c), f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += f[i];
+    }
+  *reinterpret_cast<uint4*>(dx + (((long long)b * Hi + iy) * Wi + ix) * C + c) = pack8(acc);
+}
+
+// ------------------------------------------------------------------------------ batched transpose
+// in[z][r][c] (row stride ldi, batch strides) -> out[z][c][r] (row stride ldo).  32x32 LDS tiles.
+__global__ void transpose_kernel(const act_t* __restrict__ in, act_t* __restrict__ out, int R, int Cc,
+                                 long long ldi, long long ldo, int Zi, long long sIo, long long sIi,
+                                 long long sOo, long long sOi) {
+  __shared__ act_t tile[32][33];
+  const int z = blockIdx.z, zo = z / Zi, zi = z - zo * Zi;
+  const act_t* ib = in + zo * sIo + zi * sIi;
+  act_t* ob = out + zo * sOo + zi * sOi;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8) {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < Cc) ? ib[(long long)r * ldi + c] : (act_t)0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, r = r0 + tx;
+    if (r < R && c < Cc) ob[(long long)c * ldo + r] = tile[tx][j];
+  }
+}
+
+// copy (rows, C) block into a wider channels-last tensor at channel offset (concat / slice)
+__global__ void copy_channels_kernel(const act_t* __restrict__ src, act_t* __restrict__ dst, long long rows,
+                                     int C, int lds, int ldd, int soff, int doff) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = C >> 3;
+  if (idx >= rows * cpr) return;
+  const long long r = idx / cpr;
+  const int c = (int)(idx - r * cpr) << 3;
+  *reinterpret_cast<uint4*>(dst + r * ldd + doff + c) = *reinterpret_cast<const uint4*>(src + r * lds + soff + c);
+}
+
+// y = a*x (+ b*y0)  over bf16
+__global__ void axpby_kernel(const act_t* __restrict__ x, const act_t* __restrict__ y0, act_t* __restrict__ y,
+                             float a, float b, long long n8) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n8) return;
+  float f[8], g[8];
+  unpack8(reinterpret_cast<const uint4*>(x)[idx], f);
+  if (y0) {
+    unpack8(reinterpret_cast<const uint4*>(y0)[idx], g);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = a * f[i] + b * g[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] *= a;
+  }
+  reinterpret_cast<uint4*>(y)[idx] = pack8(f);
+}
+
+// fp32 NCHW (B,C,H,W) * scale -> bf16 NHWC padded to Cp channels ;  and the reverse (+ scale)
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ x, act_t* __restrict__ y, int B, int C, int HW,
+                                             int Cp, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * HW * Cp) return;
+  const int c = (int)(idx % Cp);
+  const long long pix = idx / Cp;
+  const int b = (int)(pix / HW), p = (int)(pix - (long long)b * HW);
+  y[idx] = c < C ? f2a(x[((long long)b * C + c) * HW + p] * scale) : (act_t)0;
+}
+__global__ void nhwc_bf16_to_nchw_f32_kernel(const act_t* __restrict__ x, float* __restrict__ y, int B, int C, int HW,
+                                             int Cp, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * C * HW) return;
+  const int p = (int)(idx % HW);
+  const long long bc = idx / HW;
+  const int b = (int)(bc / C), c = (int)(bc - (long long)b * C);
+  y[idx] = a2f(x[((long long)b * HW + p) * Cp + c]) * scale;
+}
+__global__ void f32_to_bf16_kernel(const float* __restrict__ x, act_t* __restrict__ y, long long n, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) y[idx] = f2a(x[idx] * scale);
+}
+__global__ void bf16_to_f32_kernel(const act_t* __restrict__ x, float* __restrict__ y, long long n, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) y[idx] = a2f(x[idx]) * scale;
+}
+// (rows, ld) bf16 column `col` <-> (rows) fp32 vector : used for the 1-channel tensors (waveform, mel)
+__global__ void extract_col_kernel(const act_t* __restrict__ x, float* __restrict__ y, long long rows, int ld, int col) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows) y[idx] = a2f(x[idx * ld + col]);
+}
+// sinusoidal timestep embedding [cos | sin] (flip_sin_to_cos) -> bf16 (B, dim)
+__global__ void timestep_embed_kernel(const float* __restrict__ t, act_t* __restrict__ y, int B, int dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx - b * dim, half = dim >> 1;
+  const int k = j < half ? j : j - half;
+  const float e = t[b] * __expf(-9.210340371976184f * (float)k / (float)half);
+  y[idx] = f2a(j < half ? cosf(e) : sinf(e));
+}
+
+// (rows, ld) fp32 column -> (rows) fp32
+__global__ void gather_col_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long rows, int ld, int col) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows) y[idx] = x[idx * ld + col];
+}
+// gz[r, 0] = dwav[r] * (1 - wav8[r,0]^2) ; gz[r, 1..7] = 0   (bf16, 8 channels)
+__global__ void tanh_bwd_pad8_kernel(const float* __restrict__ dwav, const float* __restrict__ wav8, act_t* __restrict__ gz,
+                                     long long rows) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows) return;
+  const float w = wav8[idx * 8];
+  const float g = dwav[idx] * (1.f - w * w);
+  reinterpret_cast<uint4*>(gz)[idx] = make_uint4((uint32_t)f2a(g), 0u, 0u, 0u);
+}
+// v (rows) fp32 -> (rows, 8) bf16 with channel 0 = v*scale
+__global__ void scatter_col_pad8_kernel(const float* __restrict__ v, act_t* __restrict__ y, long long rows, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows) return;
+  reinterpret_cast<uint4*>(y)[idx] = make_uint4((uint32_t)f2a(v[idx] * scale), 0u, 0u, 0u);
+}
+
+inline void gn_geom(int P, int C, int& nt, int& rpb, int& nchunk, int& ppb) {
+  const int cpr = C >> 3;
+  rpb = cpr >= 256 ? 1 : 256 / cpr;
+  nt = cpr * rpb;
+  nchunk = cdiv(P, rpb * 8);
+  if (nchunk > DMX_GN_MAX_CHUNKS) nchunk = DMX_GN_MAX_CHUNKS;
+  if (nchunk < 1) nchunk = 1;
+  ppb = cdiv(P, nchunk);
+  nchunk = cdiv(P, ppb);
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH)
+
+size_t dmx_gn_scratch_floats(int B, int C, int G) {
+  return (size_t)B * DMX_GN_MAX_CHUNKS * G * 2;
+}
+
+int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, float* stats, float* scale,
+                      float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st) {
+  if ((C & 7) || C % G || G > 64 || C > 2048) return DMX_ERR_SHAPE;
+  int nt, rpb, nchunk, ppb;
+  gn_geom(P, C, nt, rpb, nchunk, ppb);
+  hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
+                     (const act_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial,
+                     P, C, G, rpb, ppb, 0);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, gamma, beta, stats, scale, shift, P, C, G,
+                     nchunk, ppb, eps);
+  if (y) hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, scale, shift, y, P, C, rpb, ppb, silu);
+  return CHECK_LAUNCH();
+}
+
+int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* dx, const float* stats,
+                      const float* scale, const float* shift, float* k0, float* k1, float* partial, int B, int P, int C,
+                      int G, int silu, hipStream_t st) {
+  if ((C & 7) || C % G || G > 64 || C > 2048) return DMX_ERR_SHAPE;
+  int nt, rpb, nchunk, ppb;
+  gn_geom(P, C, nt, rpb, nchunk, ppb);
+  hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x, dy,
+                     scale, shift, stats, partial, P, C, G, rpb, ppb, silu);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, partial, stats, k0, k1, P, C, G, nchunk);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, dy, scale, shift, k0, k1, add, dx, P, C,
+                     rpb, ppb, silu);
+  return CHECK_LAUNCH();
+}
+
+int dmx_layernorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
+                      hipStream_t st) {
+  if (C & 7) return DMX_ERR_SHAPE;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, gamma, beta, y, rows, C, eps);
+  return CHECK_LAUNCH();
+}
+
+int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long rows, int N, long long lds, long long ldp,
+                    int rows_per_bias, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(N >= 1024 ? 256 : 64), 0, st, S, P, colbias, N, lds, ldp,
+                     rows_per_bias < 1 ? 1 : rows_per_bias);
+  return CHECK_LAUNCH();
+}
+int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(N >= 1024 ? 256 : 64), 0, st, P, dP, dS, N, ld, scale);
+  return CHECK_LAUNCH();
+}
+int dmx_geglu(const act_t* x, act_t* y, long long rows, int I, hipStream_t st) {
+  if (I & 7) return DMX_ERR_SHAPE;
+  const long long n = rows * (I >> 3);
+  hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, rows, I);
+  return CHECK_LAUNCH();
+}
+int dmx_silu(const act_t* x, act_t* y, long long n, hipStream_t st) {
+  if (n & 7) return DMX_ERR_SHAPE;
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, x, y, n / 8);
+  return CHECK_LAUNCH();
+}
+int dmx_upsample_nearest(const act_t* x, act_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st) {
+  if (C & 7) return DMX_ERR_SHAPE;
+  const long long n = (long long)B * Ho * Wo * (C >> 3);
+  hipLaunchKernelGGL(upsample_nearest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, B, Hi, Wi, Ho, Wo, C);
+  return CHECK_LAUNCH();
+}
+int dmx_upsample2x_bwd(const act_t* dy, act_t* dx, int B, int Hi, int Wi, int C, hipStream_t st) {
+  if (C & 7) return DMX_ERR_SHAPE;
+  const long long n = (long long)B * Hi * Wi * (C >> 3);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, dx, B, Hi, Wi, C);
+  return CHECK_LAUNCH();
+}
+int dmx_transpose(const act_t* in, act_t* out, int R, int C, long long ldi, long long ldo, int Z, int Zi, long long sIo,
+                  long long sIi, long long sOo, long long sOi, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32), Z), dim3(256), 0, st, in, out, R, C, ldi, ldo, Zi,
+                     sIo, sIi, sOo, sOi);
+  return CHECK_LAUNCH();
+}
+int dmx_copy_channels(const act_t* src, act_t* dst, long long rows, int C, int lds, int ldd, int soff, int doff,
+                      hipStream_t st) {
+  if ((C & 7) || (lds & 7) || (ldd & 7) || (soff & 7) || (doff & 7)) return DMX_ERR_SHAPE;
+  const long long n = rows * (C >> 3);
+  hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, rows, C, lds,
+                     ldd, soff, doff);
+  return CHECK_LAUNCH();
+}
+int dmx_axpby(const act_t* x, const act_t* y0, act_t* y, float a, float b, long long n, hipStream_t st) {
+  if (n & 7) return DMX_ERR_SHAPE;
+  hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, st, x, y0, y, a, b, n / 8);
+  return CHECK_LAUNCH();
+}
+int dmx_nchw_f32_to_nhwc_bf16(const float* x, act_t* y, int B, int C, int HW, int Cp, float scale, hipStream_t st) {
+  const long long n = (long long)B * HW * Cp;
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, B, C, HW, Cp, scale);
+  return CHECK_LAUNCH();
+}
+int dmx_nhwc_bf16_to_nchw_f32(const act_t* x, float* y, int B, int C, int HW, int Cp, float scale, hipStream_t st) {
+  const long long n = (long long)B * C * HW;
+  hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, B, C, HW, Cp, scale);
+  return CHECK_LAUNCH();
+}
+int dmx_f32_to_bf16(const float* x, act_t* y, long long n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, scale);
+  return CHECK_LAUNCH();
+}
+int dmx_bf16_to_f32(const act_t* x, float* y, long long n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, y, n, scale);
+  return CHECK_LAUNCH();
+}
+int dmx_extract_col(const act_t* x, float* y, long long rows, int ld, int col, hipStream_t st) {
+  hipLaunchKernelGGL(extract_col_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, y, rows, ld, col);
+  return CHECK_LAUNCH();
+}
+int dmx_timestep_embed(const float* t, act_t* y, int B, int dim, hipStream_t st) {
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3(cdiv(B * dim, 256)), dim3(256), 0, st, t, y, B, dim);
+  return CHECK_LAUNCH();
+}
+
+int dmx_gather_col_f32(const float* x, float* y, long long rows, int ld, int col, hipStream_t st) {
+  hipLaunchKernelGGL(gather_col_f32_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, y, rows, ld, col);
+  return CHECK_LAUNCH();
+}
+int dmx_tanh_bwd_pad8(const float* dwav, const float* wav8, act_t* gz, long long rows, hipStream_t st) {
+  hipLaunchKernelGGL(tanh_bwd_pad8_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, dwav, wav8, gz, rows);
+  return CHECK_LAUNCH();
+}
+int dmx_scatter_col_pad8(const float* v, act_t* y, long long rows, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(scatter_col_pad8_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, v, y, rows, scale);
+  return CHECK_LAUNCH();
+}

@@ -1,0 +1,237 @@
+// Implicit-GEMM convolution / batched NT-GEMM on gfx950 MFMA (bf16 in, fp32 accumulate).
+//
+// One kernel family serves every dense contraction on the hot path ("the
+// kernel family is closed under dgrad"): conv1d (dilated), ConvTranspose1d (one launch per output
+// phase), strided conv1d (ConvTranspose dgrad), conv2d 3x3/1x1/stride-2, linear layers and the
+// attention products.  Activations are channels-last bf16 so the K axis (tap, cin) is contiguous
+// per tap; the A tile is gathered with zero fill at the borders, staged through registers into an
+// XOR-swizzled LDS image and consumed by v_mfma_f32_16x16x32_bf16 with the weight as the MFMA
+// A-operand, so each lane ends up with 4 consecutive output channels of one output pixel (8-byte
+// channels-last stores).  Everything pointwise around a contraction (bias, time-embedding row bias,
+// residual, resblock averaging, leaky-relu of the stored activation, leaky-relu' mask for dgrad,
+// tanh) is fused into the epilogue.
+#include "dmx_common.h"
+
+namespace {
+
+constexpr int BK = 64;  // bf16 elements per K-step (128 B per tile row)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int A_PER = BM * 8 / NT, B_PER = BN * 8 / NT;
+  constexpr int ROWS_PER_PASS = NT / 8;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(A_PER >= 1 && B_PER >= 1, "tile too small for the thread count");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short2* s_taps = reinterpret_cast<short2*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int z = blockIdx.y;
+  const int zo = z / p.Zi, zi = z - zo * p.Zi;
+  const act_t* __restrict__ Ab = p.A + zo * p.sAo + zi * p.sAi;
+  const act_t* __restrict__ Wb = p.W + zo * p.sWo + zi * p.sWi;
+  const long long coff = zo * p.sCo + zi * p.sCi;
+
+  if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
+
+  // ---- per-thread gather bookkeeping (rows are fixed over the K loop)
+  const int cc = tid & 7, r0 = tid >> 3;
+  const int cpt = p.Ci >> 3;  // 16-byte chunks per tap
+  const int HqWq = p.Hq * p.Wq;
+  const act_t* a_base[A_PER];
+  int a_iy[A_PER], a_ix[A_PER];
+#pragma unroll
+  for (int i = 0; i < A_PER; ++i) {
+    const int m = tm * BM + r0 + i * ROWS_PER_PASS;
+    if (m < p.M) {
+      const int b = m / HqWq, rem = m - b * HqWq;
+      const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+      a_base[i] = Ab + (long long)b * p.Hi * p.Wi * p.lda;
+      a_iy[i] = qy * p.sy;
+      a_ix[i] = qx * p.sx;
+    } else {
+      a_base[i] = Ab;
+      a_iy[i] = -(1 << 20);
+      a_ix[i] = 0;
+    }
+  }
+  const act_t* w_base[B_PER];
+  bool w_ok[B_PER];
+#pragma unroll
+  for (int i = 0; i < B_PER; ++i) {
+    const int n = tn * BN + r0 + i * ROWS_PER_PASS;
+    w_ok[i] = n < p.N;
+    w_base[i] = Wb + (long long)(w_ok[i] ? n : 0) * p.ldw;
+  }
+  __syncthreads();  // taps visible
+
+  uint4 ra[A_PER], rb[B_PER];
+  const int kchunks = p.K >> 3;
+  auto load_tile = [&](int ks) {
+    const int kc = ks * 8 + cc;
+    const int tap = kc / cpt;
+    const int cin = (kc - tap * cpt) << 3;
+    const bool kval = kc < kchunks;
+    const short2 t = s_taps[tap & (DMX_MAX_TAPS - 1)];
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int iy = a_iy[i] + t.x, ix = a_ix[i] + t.y;
+      const bool ok = kval && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(a_base[i] + (long long)(iy * p.Wi + ix) * p.lda + cin);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (kval && w_ok[i]) rb[i] = *reinterpret_cast<const uint4*>(w_base[i] + (kc << 3));
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* sa = smem + buf * STAGE;
+    char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int r = r0 + i * ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sa + r * 128 + ((cc ^ (r & 7)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int r = r0 + i * ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sb + r * 128 + ((cc ^ (r & 7)) << 4)) = rb[i];
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) load_tile(ks + 1);
+    const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
+    const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = ((kk * 4 + lq) ^ (lr & 7)) << 4;
+      frag8_t af[FM], wf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const frag8_t*>(sb + j * 16 * 128 + sw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = DMX_MFMA16(wf[j], af[i], acc[i][j]);
+    }
+    if (ks + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = n0 + 4*lq + {0..3} for pixel row m = .. + lr
+  const int flags = p.flags;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = tm * BM + wm * TM + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int b = m / HqWq, rem = m - b * HqWq;
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const long long orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = tn * BN + wn * TN + j * 16 + lq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (flags & EPI_MASK) {
+        const uint2 xr = *reinterpret_cast<const uint2*>(p.X + coff + orow * p.ldx + n);
+        const float s = p.mask_slope;
+        v[0] *= (alo(xr.x) > 0.f) ? 1.f : s;
+        v[1] *= (ahi(xr.x) > 0.f) ? 1.f : s;
+        v[2] *= (alo(xr.y) > 0.f) ? 1.f : s;
+        v[3] *= (ahi(xr.y) > 0.f) ? 1.f : s;
+      }
+      if (flags & EPI_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_ROWBIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * p.N + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_RESID) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.R + coff + orow * p.ldr + n);
+        v[0] += alo(rr.x); v[1] += ahi(rr.x); v[2] += alo(rr.y); v[3] += ahi(rr.y);
+      }
+      const float al = p.alpha;
+      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+      if (flags & EPI_F32OUT) {
+        float* cp = reinterpret_cast<float*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const float4 o = *reinterpret_cast<const float4*>(cp);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        act_t* cp = reinterpret_cast<act_t*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const uint2 o = *reinterpret_cast<const uint2*>(cp);
+          v[0] += alo(o.x); v[1] += ahi(o.x); v[2] += alo(o.y); v[3] += ahi(o.y);
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        if (!(flags & EPI_NO_C)) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
+      }
+      if (flags & EPI_LRELU2) {
+        const float s = p.act_slope;
+        const float a0 = v[0] > 0.f ? v[0] : v[0] * s, a1 = v[1] > 0.f ? v[1] : v[1] * s;
+        const float a2 = v[2] > 0.f ? v[2] : v[2] * s, a3 = v[3] > 0.f ? v[3] : v[3] * s;
+        *reinterpret_cast<uint2*>(p.C2 + coff + orow * p.ldc2 + n) = make_uint2(pack2a(a0, a1), pack2a(a2, a3));
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmDesc& d, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(NT), SMEM, stream, d);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
+}  // namespace
+
+int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return DMX_ERR_SHAPE;
+  if ((d.Ci & 7) || (d.N & 3) || (d.K & 7) || (d.lda & 7) || (d.ldw & 7) || (d.ldc & 3)) return DMX_ERR_SHAPE;
+  if (d.ntaps < 1 || d.ntaps > DMX_MAX_TAPS || d.K != d.ntaps * d.Ci) return DMX_ERR_SHAPE;
+  if (d.Z < 1 || d.Zi < 1) return DMX_ERR_SHAPE;
+  if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
+  if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
+  return launch_cfg<128, 32, 4, 1>(d, stream);
+}

@@ -1,0 +1,221 @@
+// HiFi-GAN vocoder forward + input-gradient backward on the implicit-GEMM kernel.
+// Semantics follow transformers SpeechT5HifiGan.forward (modeling_speecht5.py:3010-3069), which the
+// reference calls inside every guided step through BaseOperator.inverse_transform
+// (diffmusic/inverse_problem/operator.py:126-130; gradient path scheduling_dps.py:195-212).
+//
+// No autograd tape: the only state kept for the backward pass is the leaky-relu'd activation that
+// each convolution consumed (its sign is the leaky-relu' mask; sign(lrelu(x)) == sign(x)), and the
+// tanh output.  Weights never receive gradients, so dgrad needs no saved conv inputs.
+#include "models.h"
+
+struct HifiGan : Model {
+  dmx_hifigan_config cfg;
+  ConvLayer conv_pre, conv_post;
+  std::vector<ConvLayer> ups;
+  std::vector<ConvLayer> c1, c2;  // [stage][kernel][dil] flattened
+  int nk = 0, nd = 0, ns = 0;
+  // tape
+  int B = 0, T = 0;
+  std::vector<int> Ts;                 // length after each stage
+  act_t* act_pre = nullptr;           // lrelu(conv_pre(mel))
+  std::vector<act_t*> xs_a;           // [stage] lrelu(upsampler out)
+  std::vector<act_t*> ha, xa;         // [stage][kernel][dil]
+  std::vector<act_t*> act_out;        // [stage] lrelu(stage output) (slope of the consumer)
+  float* wav8 = nullptr;               // (B, Tout, 8) fp32 tanh output, channel 0 real
+  bool have_tape = false;
+
+  int idx(int s, int k, int d) const { return (s * nk + k) * nd + d; }
+
+  explicit HifiGan(const dmx_hifigan_config& c) : cfg(c) {
+    kind = DMX_MODEL_HIFIGAN;
+    ns = c.num_upsamples; nk = c.num_kernels; nd = c.num_dilations;
+    const int C0 = c.upsample_initial_channel;
+    conv_pre = make_conv1d(ps, "conv_pre", c.model_in_dim, C0, 7, 1, 3, true);
+    for (int i = 0; i < ns; ++i) {
+      const int s = c.upsample_rates[i], k = c.upsample_kernel_sizes[i];
+      ups.push_back(make_convT1d(ps, "upsampler." + std::to_string(i), C0 >> i, C0 >> (i + 1), k, s, (k - s) / 2, true));
+    }
+    int ch = C0;
+    for (int i = 0; i < ns; ++i) {
+      ch = C0 >> (i + 1);
+      for (int j = 0; j < nk; ++j) {
+        const int k = c.resblock_kernel_sizes[j];
+        const std::string pre = "resblocks." + std::to_string(i * nk + j);
+        for (int d = 0; d < nd; ++d) {
+          const int dil = c.resblock_dilation_sizes[j * nd + d];
+          c1.push_back(make_conv1d(ps, pre + ".convs1." + std::to_string(d), ch, ch, k, dil, (k * dil - dil) / 2, true));
+          c2.push_back(make_conv1d(ps, pre + ".convs2." + std::to_string(d), ch, ch, k, 1, (k - 1) / 2, true));
+        }
+      }
+    }
+    conv_post = make_conv1d(ps, "conv_post", ch, 1, 7, 1, 3, true);
+  }
+
+  int finalize(hipStream_t st) override {
+    int rc = pack_layer(ps, conv_pre, st);
+    for (auto& l : ups) if (rc == DMX_OK) rc = pack_layer(ps, l, st);
+    for (auto& l : c1) if (rc == DMX_OK) rc = pack_layer(ps, l, st);
+    for (auto& l : c2) if (rc == DMX_OK) rc = pack_layer(ps, l, st);
+    if (rc == DMX_OK) rc = pack_layer(ps, conv_post, st);
+    return rc;
+  }
+
+  int out_len(int T_) const {
+    int t = T_;
+    for (int i = 0; i < ns; ++i) t = conv_out_len(ups[i], t);
+    return t;
+  }
+
+  // mel: (B, T, model_in_dim) bf16 ; wav: (B, Tout) fp32
+  int forward(const act_t* mel, float* wav, int B_, int T_, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (cfg.model_in_dim & 7) return DMX_ERR_SHAPE;
+    dry = (ws == nullptr);
+    arena.reset(ws, dry ? (size_t)-1 : ws_bytes);
+    B = B_; T = T_;
+    Ts.assign(ns, 0);
+    xs_a.assign(ns, nullptr); act_out.assign(ns, nullptr);
+    ha.assign(ns * nk * nd, nullptr); xa.assign(ns * nk * nd, nullptr);
+    const float slope = cfg.leaky_relu_slope;
+    // conv_pre -> only the activated tensor is needed downstream
+    act_pre = arena.bf((size_t)B * T * conv_pre.Cop);
+    {
+      Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = act_pre;
+      RUN(conv_fwd_1d(conv_pre, mel, act_pre, B, T, e, st));
+    }
+    const act_t* cur_act = act_pre;
+    int Tin = T;
+    for (int s = 0; s < ns; ++s) {
+      const ConvLayer& up = ups[s];
+      const int To = conv_out_len(up, Tin), C = up.Cop;
+      const size_t n = (size_t)B * To * C;
+      Ts[s] = To;
+      xs_a[s] = arena.bf(n);
+      act_out[s] = arena.bf(n);
+      for (int k = 0; k < nk; ++k)
+        for (int d = 0; d < nd; ++d) {
+          ha[idx(s, k, d)] = arena.bf(n);
+          xa[idx(s, k, d)] = d == 0 ? xs_a[s] : arena.bf(n);
+        }
+      const size_t mk = arena.mark();       // transients below are released per stage
+      act_t* xs = arena.bf(n);
+      act_t* xA = arena.bf(n);
+      act_t* xB = arena.bf(n);
+      act_t* sum = arena.bf(n);
+      {
+        Epi e; e.flags = EPI_LRELU2; e.act_slope = slope; e.C2 = xs_a[s];
+        RUN(conv_fwd_1d(up, cur_act, xs, B, Tin, e, st));
+      }
+      const float next_slope = (s == ns - 1) ? 0.01f : slope;
+      for (int k = 0; k < nk; ++k) {
+        const act_t* x = xs;
+        for (int d = 0; d < nd; ++d) {
+          const int id = idx(s, k, d);
+          {
+            Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = ha[id];
+            RUN(conv_fwd_1d(c1[id], xa[id], ha[id], B, To, e, st));
+          }
+          if (d < nd - 1) {
+            act_t* xn = (d & 1) ? xB : xA;
+            Epi e; e.flags = EPI_RESID | EPI_LRELU2; e.R = x; e.act_slope = slope; e.C2 = xa[idx(s, k, d + 1)];
+            RUN(conv_fwd_1d(c2[id], ha[id], xn, B, To, e, st));
+            x = xn;
+          } else {
+            Epi e; e.flags = EPI_RESID; e.R = x; e.alpha = 1.f / nk;
+            if (k > 0) e.flags |= EPI_ACCUM;
+            if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
+            RUN(conv_fwd_1d(c2[id], ha[id], sum, B, To, e, st));
+          }
+        }
+      }
+      arena.release(mk);
+      cur_act = act_out[s];
+      Tin = To;
+    }
+    const int Tout = Tin;
+    wav8 = arena.f32((size_t)B * Tout * 8);
+    CHECK_WS("hifigan");
+    {
+      Epi e; e.flags = EPI_F32OUT | EPI_TANH;
+      RUN(conv_fwd_1d(conv_post, cur_act, wav8, B, Tout, e, st));
+    }
+    RUN(dmx_gather_col_f32(wav8, wav, (long long)B * Tout, 8, 0, st));
+    have_tape = true;
+    return DMX_OK;
+  }
+
+  // dwav: (B, Tout) fp32 -> dmel: (B, T, model_in_dim) bf16.  Uses the tape of the last forward.
+  int backward(const float* dwav, act_t* dmel, hipStream_t st) {
+    if (!have_tape && !dry) { dmx_set_error("hifigan backward without forward"); return DMX_ERR_STATE; }
+    const float slope = cfg.leaky_relu_slope;
+    const int Tout = Ts[ns - 1];
+    const size_t mk0 = arena.mark();
+    // d tanh: gz = dwav * (1 - wav^2), padded to 8 channels
+    act_t* gz = arena.bf((size_t)B * Tout * 8);
+    const int Clast = ups[ns - 1].Cop;
+    act_t* g = arena.bf((size_t)B * Tout * Clast);      // grad wrt each resblock output of the last stage
+    CHECK_WS("hifigan");
+    RUN(dmx_tanh_bwd_pad8(dwav, wav8, gz, (long long)B * Tout, st));
+    {
+      Epi e; e.flags = EPI_MASK; e.X = act_out[ns - 1]; e.mask_slope = 0.01f; e.alpha = 1.f / nk;
+      RUN(conv_bwd_1d(conv_post, gz, g, B, Tout, e, st));
+    }
+    for (int s = ns - 1; s >= 0; --s) {
+      const int To = Ts[s], Tin = s == 0 ? T : Ts[s - 1], C = ups[s].Cop;
+      const size_t n = (size_t)B * To * C;
+      act_t* gxs = arena.bf(n);
+      act_t* gh = arena.bf(n);
+      act_t* gA = arena.bf(n);
+      act_t* gB = arena.bf(n);
+      const int Cin = ups[s].Cip;
+      act_t* gprev = arena.bf((size_t)B * Tin * Cin);
+      CHECK_WS("hifigan");
+      for (int k = 0; k < nk; ++k) {
+        const act_t* gc = g;
+        for (int d = nd - 1; d >= 0; --d) {
+          const int id = idx(s, k, d);
+          {
+            Epi e; e.flags = EPI_MASK; e.X = ha[id]; e.mask_slope = slope;
+            RUN(conv_bwd_1d(c2[id], gc, gh, B, To, e, st));
+          }
+          Epi e; e.flags = EPI_MASK | EPI_RESID; e.X = xa[id]; e.mask_slope = slope; e.R = gc;
+          act_t* dst;
+          if (d == 0) { dst = gxs; if (k > 0) e.flags |= EPI_ACCUM; }
+          else dst = (gc == gA) ? gB : gA;
+          RUN(conv_bwd_1d(c1[id], gh, dst, B, To, e, st));
+          gc = dst;
+        }
+      }
+      // through the upsampler (strided conv) and the leaky-relu that fed it
+      {
+        Epi e; e.flags = EPI_MASK; e.mask_slope = slope;
+        if (s > 0) { e.X = act_out[s - 1]; e.alpha = 1.f / nk; } else { e.X = act_pre; }
+        RUN(conv_bwd_1d(ups[s], gxs, gprev, B, Tin, e, st));
+      }
+      g = gprev;   // (buffers of this stage stay allocated until the end of backward; sizes shrink geometrically)
+    }
+    {
+      Epi e;
+      RUN(conv_bwd_1d(conv_pre, g, dmel, B, T, e, st));
+    }
+    arena.release(mk0);
+    return DMX_OK;
+  }
+};
+
+Model* dmx_make_hifigan(const dmx_hifigan_config* c) { return new HifiGan(*c); }
+int dmx_hifigan_out_len_impl(Model* m, int T) { return static_cast<HifiGan*>(m)->out_len(T); }
+int dmx_hifigan_fwd_impl(Model* m, const act_t* mel, float* wav, int B, int T, void* ws, size_t wsb, hipStream_t st) {
+  return static_cast<HifiGan*>(m)->forward(mel, wav, B, T, ws, wsb, st);
+}
+int dmx_hifigan_bwd_impl(Model* m, const float* dwav, act_t* dmel, hipStream_t st) {
+  return static_cast<HifiGan*>(m)->backward(dwav, dmel, st);
+}
+size_t dmx_hifigan_ws_impl(Model* m, int B, int T) {
+  HifiGan* h = static_cast<HifiGan*>(m);
+  h->arena.peak = 0;
+  h->forward(nullptr, nullptr, B, T, nullptr, 0, nullptr);
+  h->backward(nullptr, nullptr, nullptr);
+  h->have_tape = false;
+  h->dry = false;
+  return h->arena.peak + 256;
+}

@@ -1,0 +1,106 @@
+// Host-side layer plumbing shared by the three network executors (hifigan.cpp, vae.cpp, unet.cpp):
+// parameter registry, workspace arena, packed conv layers and the GemmDesc builders.
+#pragma once
+#include <string>
+#include <vector>
+#include <map>
+#include <cstdio>
+#include <cstring>
+#include "dmx_common.h"
+#include "kernels.h"
+
+void dmx_set_error(const char* fmt, ...);
+
+inline int pad8(int c) { return (c + 7) & ~7; }
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool overflow = false;
+  void reset(void* b, size_t c) { base = (char*)b; cap = c; off = 0; overflow = false; }
+  void* raw(size_t bytes) {
+    bytes = align_up(bytes, 256);
+    if (off + bytes > cap) { overflow = true; off += bytes; if (off > peak) peak = off; return base; }  // keep counting
+    void* p = base + off;
+    off += bytes;
+    if (off > peak) peak = off;
+    return p;
+  }
+  act_t* bf(size_t n) { return (act_t*)raw(n * 2); }
+  float* f32(size_t n) { return (float*)raw(n * 4); }
+  size_t mark() const { return off; }
+  void release(size_t m) { off = m; }
+};
+
+struct Param {
+  std::string name;
+  std::vector<int> shape;
+  size_t numel = 0;
+  float* dev = nullptr;  // fp32 copy on device
+  bool loaded = false;
+};
+
+struct ParamStore {
+  std::vector<Param> params;
+  std::map<std::string, int> index;
+  std::vector<void*> owned;  // device allocations freed on destroy
+  int add(const std::string& name, std::vector<int> shape);
+  float* dev(int id) const { return params[id].dev; }
+  int load(const char* name, const float* host, size_t numel);
+  bool all_loaded(std::string* missing) const;
+  void* dalloc(size_t bytes);
+  void free_all();
+};
+
+// A convolution (1-D, 2-D, transposed 1-D) or linear layer prepared for the implicit-GEMM kernel.
+struct ConvLayer {
+  int Ci = 0, Co = 0, Cip = 0, Cop = 0;
+  int kh = 1, kw = 1, stride = 1, dil = 1, pad_h = 0, pad_w = 0;
+  bool transposed = false;  // ConvTranspose1d (weight layout Cin,Cout,k)
+  bool has_bias = true, need_bwd = false;
+  int w_id = -1, b_id = -1;
+  // packed
+  std::vector<act_t*> wf;          // forward weights (one per output phase for transposed)
+  std::vector<std::vector<int>> wf_taps;  // tap index list per phase (transposed)
+  act_t* wb = nullptr;             // dgrad weights
+  float* bias = nullptr;            // fp32 [Cop]
+  int ntaps() const { return kh * kw; }
+};
+
+struct Epi {
+  int flags = 0;
+  float alpha = 1.f, act_slope = 0.f, mask_slope = 0.f;
+  const act_t* R = nullptr;
+  const act_t* X = nullptr;
+  act_t* C2 = nullptr;
+  const float* rowbias = nullptr;
+};
+
+// registry helpers
+ConvLayer make_conv1d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int dil, int pad, bool need_bwd);
+ConvLayer make_convT1d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int stride, int pad, bool need_bwd);
+ConvLayer make_conv2d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int stride, int pad, bool need_bwd);
+ConvLayer make_linear(ParamStore& ps, const std::string& prefix, int Ci, int Co, bool bias, bool need_bwd);
+int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st);
+
+// launches.  Tensors are channels-last with padded channel counts (Cip / Cop).
+// 1-D: in (B, Ti, Cip) -> out (B, To, Cop);  2-D: in (B, Hi, Wi, Cip) -> out (B, Ho, Wo, Cop)
+int conv_out_len(const ConvLayer& L, int Ti);
+int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, hipStream_t st);
+int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, hipStream_t st);
+int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
+int conv_bwd_2d(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
+// plain (batched) NT GEMM: C[z] = alpha * A[z] (M,K; lda) * Bm[z]^T (N,K; ldb)  (+ epilogue)
+struct GemmBatch { int Z = 1, Zi = 1; long long sAo = 0, sAi = 0, sBo = 0, sBi = 0, sCo = 0, sCi = 0; };
+int gemm_nt(const act_t* A, int lda, const act_t* Bm, int ldb, void* C, int ldc, int M, int N, int K, const Epi& e,
+            const GemmBatch& gb, hipStream_t st);
+// linear layer on (rows, Cip) -> (rows, Cop)
+int linear_fwd(const ConvLayer& L, const act_t* in, int lda, void* out, int ldc, long long rows, const Epi& e, hipStream_t st);
+int linear_bwd(const ConvLayer& L, const act_t* dout, int lda, void* din, int ldc, long long rows, const Epi& e, hipStream_t st);
+
+struct GroupNormLayer {
+  int C = 0, G = 32, g_id = -1, b_id = -1;
+  float eps = 1e-5f;
+};
+GroupNormLayer make_gn(ParamStore& ps, const std::string& prefix, int C, int G, float eps);
+struct GnSave { float* stats = nullptr; float* scale = nullptr; float* shift = nullptr; };

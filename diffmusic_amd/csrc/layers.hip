@@ -1,0 +1,290 @@
+// Parameter registry, weight packing and GemmDesc builders (see layers.h).
+#include "layers.h"
+#include <cstdarg>
+
+static thread_local char g_err[512] = "";
+void dmx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* dmx_last_error() { return g_err; }
+
+// ------------------------------------------------------------------------------ ParamStore
+int ParamStore::add(const std::string& name, std::vector<int> shape) {
+  Param p;
+  p.name = name;
+  p.shape = shape;
+  p.numel = 1;
+  for (int s : shape) p.numel *= (size_t)s;
+  p.dev = (float*)dalloc(p.numel * sizeof(float));
+  index[name] = (int)params.size();
+  params.push_back(p);
+  return (int)params.size() - 1;
+}
+void* ParamStore::dalloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { dmx_set_error("hipMalloc(%zu) failed", bytes); return nullptr; }
+  owned.push_back(p);
+  return p;
+}
+int ParamStore::load(const char* name, const float* host, size_t numel) {
+  auto it = index.find(name);
+  if (it == index.end()) { dmx_set_error("unknown parameter '%s'", name); return DMX_ERR_PARAM; }
+  Param& p = params[it->second];
+  if (p.numel != numel) { dmx_set_error("parameter '%s': expected %zu elements, got %zu", name, p.numel, numel); return DMX_ERR_PARAM; }
+  if (hipMemcpy(p.dev, host, numel * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    dmx_set_error("hipMemcpy failed for '%s'", name);
+    return DMX_ERR_PARAM;
+  }
+  p.loaded = true;
+  return DMX_OK;
+}
+bool ParamStore::all_loaded(std::string* missing) const {
+  for (const Param& p : params)
+    if (!p.loaded) { if (missing) *missing = p.name; return false; }
+  return true;
+}
+void ParamStore::free_all() {
+  for (void* p : owned) (void)hipFree(p);
+  owned.clear();
+}
+
+// ------------------------------------------------------------------------------ packing
+struct PackTaps { int idx[DMX_MAX_TAPS]; };
+__global__ void pack_weight_kernel(const float* __restrict__ src, act_t* __restrict__ dst, int Np, int Nreal, int T, int Cp,
+                                   int Creal, long long sn, long long sc, long long st, PackTaps taps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)Np * T * Cp;
+  if (idx >= total) return;
+  const int c = (int)(idx % Cp);
+  const int t = (int)((idx / Cp) % T);
+  const int n = (int)(idx / ((long long)Cp * T));
+  float v = 0.f;
+  if (n < Nreal && c < Creal && taps.idx[t] >= 0) v = src[n * sn + c * sc + taps.idx[t] * st];
+  dst[idx] = f2a(v);
+}
+__global__ void pad_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < np) dst[i] = (src && i < n) ? src[i] : 0.f;
+}
+
+static act_t* pack(ParamStore& ps, const float* src, int Np, int Nreal, int T, int Cp, int Creal, long long sn, long long sc,
+                    long long st_, const std::vector<int>& tapidx, hipStream_t st) {
+  const long long total = (long long)Np * T * Cp;
+  act_t* dst = (act_t*)ps.dalloc(total * 2);
+  if (!dst) return nullptr;
+  PackTaps pt;
+  for (int i = 0; i < DMX_MAX_TAPS; ++i) pt.idx[i] = i < (int)tapidx.size() ? tapidx[i] : -1;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, Np, Nreal, T, Cp,
+                     Creal, sn, sc, st_, pt);
+  return dst;
+}
+
+static ConvLayer base_layer(ParamStore& ps, const std::string& prefix, std::vector<int> wshape, int Co, bool bias) {
+  ConvLayer L;
+  L.w_id = ps.add(prefix + ".weight", wshape);
+  L.has_bias = bias;
+  if (bias) L.b_id = ps.add(prefix + ".bias", {Co});
+  return L;
+}
+ConvLayer make_conv1d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int dil, int pad, bool need_bwd) {
+  ConvLayer L = base_layer(ps, prefix, {Co, Ci, k}, Co, true);
+  L.Ci = Ci; L.Co = Co; L.Cip = pad8(Ci); L.Cop = pad8(Co);
+  L.kh = 1; L.kw = k; L.dil = dil; L.pad_w = pad; L.need_bwd = need_bwd;
+  return L;
+}
+ConvLayer make_convT1d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int stride, int pad, bool need_bwd) {
+  ConvLayer L = base_layer(ps, prefix, {Ci, Co, k}, Co, true);
+  L.Ci = Ci; L.Co = Co; L.Cip = pad8(Ci); L.Cop = pad8(Co);
+  L.kh = 1; L.kw = k; L.stride = stride; L.pad_w = pad; L.transposed = true; L.need_bwd = need_bwd;
+  return L;
+}
+ConvLayer make_conv2d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int stride, int pad, bool need_bwd) {
+  ConvLayer L = base_layer(ps, prefix, {Co, Ci, k, k}, Co, true);
+  L.Ci = Ci; L.Co = Co; L.Cip = pad8(Ci); L.Cop = pad8(Co);
+  L.kh = k; L.kw = k; L.stride = stride; L.pad_h = pad; L.pad_w = pad; L.need_bwd = need_bwd;
+  return L;
+}
+ConvLayer make_linear(ParamStore& ps, const std::string& prefix, int Ci, int Co, bool bias, bool need_bwd) {
+  ConvLayer L = base_layer(ps, prefix, {Co, Ci}, Co, bias);
+  L.Ci = Ci; L.Co = Co; L.Cip = pad8(Ci); L.Cop = pad8(Co);
+  L.need_bwd = need_bwd;
+  return L;
+}
+GroupNormLayer make_gn(ParamStore& ps, const std::string& prefix, int C, int G, float eps) {
+  GroupNormLayer g;
+  g.C = C; g.G = G; g.eps = eps;
+  g.g_id = ps.add(prefix + ".weight", {C});
+  g.b_id = ps.add(prefix + ".bias", {C});
+  return g;
+}
+
+int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
+  const float* w = ps.dev(L.w_id);
+  const int T = L.ntaps();
+  if (T > DMX_MAX_TAPS) { dmx_set_error("too many taps"); return DMX_ERR_SHAPE; }
+  std::vector<int> all(T);
+  for (int i = 0; i < T; ++i) all[i] = i;
+  if (!L.transposed) {
+    // W[Co][Ci][T]
+    L.wf.push_back(pack(ps, w, L.Cop, L.Co, T, L.Cip, L.Ci, (long long)L.Ci * T, T, 1, all, st));
+    if (L.need_bwd) L.wb = pack(ps, w, L.Cip, L.Ci, T, L.Cop, L.Co, T, (long long)L.Ci * T, 1, all, st);
+  } else {
+    // W[Ci][Co][k]; one packed matrix per output phase
+    const int k = L.kw, s = L.stride, p = L.pad_w;
+    for (int r = 0; r < s; ++r) {
+      const int j0 = (r + p) % s;
+      std::vector<int> taps;
+      for (int j = j0; j < k; j += s) taps.push_back(j);
+      L.wf_taps.push_back(taps);
+      L.wf.push_back(pack(ps, w, L.Cop, L.Co, (int)taps.size(), L.Cip, L.Ci, k, (long long)L.Co * k, 1, taps, st));
+    }
+    if (L.need_bwd) L.wb = pack(ps, w, L.Cip, L.Ci, k, L.Cop, L.Co, (long long)L.Co * k, k, 1, all, st);
+  }
+  L.bias = (float*)ps.dalloc(L.Cop * sizeof(float));
+  hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(L.Cop, 256)), dim3(256), 0, st, L.has_bias ? ps.dev(L.b_id) : (const float*)nullptr,
+                     L.bias, L.Co, L.Cop);
+  for (act_t* pw : L.wf) if (!pw) return DMX_ERR_PARAM;
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------ descriptors
+static void init_desc(GemmDesc& d, const Epi& e) {
+  memset(&d, 0, sizeof(d));
+  d.Z = 1; d.Zi = 1;
+  d.sy = d.sx = 1; d.osy = d.osx = 1;
+  d.alpha = e.alpha; d.act_slope = e.act_slope; d.mask_slope = e.mask_slope;
+  d.flags = e.flags;
+  d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias;
+}
+static void set_out(GemmDesc& d, void* C, int Ho, int Wo, int ldc) {
+  d.C = C; d.Ho = Ho; d.Wo = Wo; d.ldc = d.ldr = d.ldx = d.ldc2 = ldc;
+}
+
+int conv_out_len(const ConvLayer& L, int Ti) {
+  if (L.transposed) return (Ti - 1) * L.stride - 2 * L.pad_w + L.kw;
+  return (Ti + 2 * L.pad_w - L.dil * (L.kw - 1) - 1) / L.stride + 1;
+}
+
+int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, hipStream_t st) {
+  const int To = conv_out_len(L, Ti);
+  GemmDesc d;
+  init_desc(d, e);
+  if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
+  d.A = in; d.Hi = 1; d.Wi = Ti; d.Ci = L.Cip; d.lda = L.Cip;
+  d.N = L.Cop;
+  set_out(d, out, 1, To, L.Cop);
+  if (!L.transposed) {
+    d.W = L.wf[0]; d.ntaps = L.kw; d.K = L.kw * L.Cip; d.ldw = d.K;
+    d.Hq = 1; d.Wq = To; d.sx = L.stride; d.M = B * To;
+    for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(t * L.dil - L.pad_w); }
+    return dmx_gemm_launch(d, st);
+  }
+  const int s = L.stride, p = L.pad_w;
+  for (int r = 0; r < s; ++r) {
+    GemmDesc q = d;
+    const int nt = (int)L.wf_taps[r].size();
+    const int base = (r + p) / s;
+    q.W = L.wf[r]; q.ntaps = nt; q.K = nt * L.Cip; q.ldw = q.K;
+    q.Hq = 1; q.Wq = cdiv(To - r, s); q.M = B * q.Wq;
+    q.osx = s; q.oox = r;
+    for (int i = 0; i < nt; ++i) { q.tdy[i] = 0; q.tdx[i] = (signed char)(base - i); }
+    if (q.Wq <= 0) continue;
+    const int rc = dmx_gemm_launch(q, st);
+    if (rc != DMX_OK) return rc;
+  }
+  return DMX_OK;
+}
+
+// dgrad: dout (B, To, Cop) -> din (B, Ti, Cip)
+int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, hipStream_t st) {
+  if (!L.wb) { dmx_set_error("layer has no dgrad weights"); return DMX_ERR_STATE; }
+  const int To = conv_out_len(L, Ti);
+  GemmDesc d;
+  init_desc(d, e);
+  d.A = dout; d.Hi = 1; d.Wi = To; d.Ci = L.Cop; d.lda = L.Cop;
+  d.W = L.wb; d.ntaps = L.kw; d.K = L.kw * L.Cop; d.ldw = d.K;
+  d.N = L.Cip;
+  d.Hq = 1; d.Wq = Ti; d.M = B * Ti;
+  set_out(d, din, 1, Ti, L.Cip);
+  if (!L.transposed) {
+    if (L.stride != 1) return DMX_ERR_SHAPE;
+    for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(L.pad_w - t * L.dil); }
+  } else {
+    d.sx = L.stride;
+    for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(t - L.pad_w); }
+  }
+  return dmx_gemm_launch(d, st);
+}
+
+int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {
+  const int Ho = (Hi + 2 * L.pad_h - L.kh) / L.stride + 1, Wo = (Wi + 2 * L.pad_w - L.kw) / L.stride + 1;
+  GemmDesc d;
+  init_desc(d, e);
+  if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
+  d.A = in; d.Hi = Hi; d.Wi = Wi; d.Ci = L.Cip; d.lda = L.Cip;
+  d.W = L.wf[0]; d.ntaps = L.kh * L.kw; d.K = d.ntaps * L.Cip; d.ldw = d.K;
+  d.N = L.Cop; d.Hq = Ho; d.Wq = Wo; d.sy = d.sx = L.stride; d.M = B * Ho * Wo;
+  set_out(d, out, Ho, Wo, L.Cop);
+  for (int ky = 0; ky < L.kh; ++ky)
+    for (int kx = 0; kx < L.kw; ++kx) {
+      d.tdy[ky * L.kw + kx] = (signed char)(ky - L.pad_h);
+      d.tdx[ky * L.kw + kx] = (signed char)(kx - L.pad_w);
+    }
+  return dmx_gemm_launch(d, st);
+}
+
+int conv_bwd_2d(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {
+  if (!L.wb) { dmx_set_error("layer has no dgrad weights"); return DMX_ERR_STATE; }
+  if (L.stride != 1) return DMX_ERR_SHAPE;
+  const int Ho = Hi + 2 * L.pad_h - L.kh + 1, Wo = Wi + 2 * L.pad_w - L.kw + 1;
+  GemmDesc d;
+  init_desc(d, e);
+  d.A = dout; d.Hi = Ho; d.Wi = Wo; d.Ci = L.Cop; d.lda = L.Cop;
+  d.W = L.wb; d.ntaps = L.kh * L.kw; d.K = d.ntaps * L.Cop; d.ldw = d.K;
+  d.N = L.Cip; d.Hq = Hi; d.Wq = Wi; d.M = B * Hi * Wi;
+  set_out(d, din, Hi, Wi, L.Cip);
+  for (int ky = 0; ky < L.kh; ++ky)
+    for (int kx = 0; kx < L.kw; ++kx) {
+      d.tdy[ky * L.kw + kx] = (signed char)(L.pad_h - ky);
+      d.tdx[ky * L.kw + kx] = (signed char)(L.pad_w - kx);
+    }
+  return dmx_gemm_launch(d, st);
+}
+
+int gemm_nt(const act_t* A, int lda, const act_t* Bm, int ldb, void* C, int ldc, int M, int N, int K, const Epi& e,
+            const GemmBatch& gb, hipStream_t st) {
+  GemmDesc d;
+  init_desc(d, e);
+  d.A = A; d.Hi = 1; d.Wi = M; d.Ci = K; d.lda = lda;
+  d.W = Bm; d.ntaps = 1; d.K = K; d.ldw = ldb;
+  d.N = N; d.Hq = 1; d.Wq = M; d.M = M;
+  set_out(d, C, 1, M, ldc);
+  d.Z = gb.Z; d.Zi = gb.Zi;
+  d.sAo = gb.sAo; d.sAi = gb.sAi; d.sWo = gb.sBo; d.sWi = gb.sBi; d.sCo = gb.sCo; d.sCi = gb.sCi;
+  return dmx_gemm_launch(d, st);
+}
+
+int linear_fwd(const ConvLayer& L, const act_t* in, int lda, void* out, int ldc, long long rows, const Epi& e, hipStream_t st) {
+  Epi ee = e;
+  GemmDesc d;
+  init_desc(d, ee);
+  if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
+  d.A = in; d.Hi = 1; d.Wi = (int)rows; d.Ci = L.Cip; d.lda = lda;
+  d.W = L.wf[0]; d.ntaps = 1; d.K = L.Cip; d.ldw = L.Cip;
+  d.N = L.Cop; d.Hq = 1; d.Wq = (int)rows; d.M = (int)rows;
+  set_out(d, out, 1, (int)rows, ldc);
+  return dmx_gemm_launch(d, st);
+}
+int linear_bwd(const ConvLayer& L, const act_t* dout, int lda, void* din, int ldc, long long rows, const Epi& e, hipStream_t st) {
+  if (!L.wb) { dmx_set_error("layer has no dgrad weights"); return DMX_ERR_STATE; }
+  GemmDesc d;
+  init_desc(d, e);
+  d.A = dout; d.Hi = 1; d.Wi = (int)rows; d.Ci = L.Cop; d.lda = lda;
+  d.W = L.wb; d.ntaps = 1; d.K = L.Cop; d.ldw = L.Cop;
+  d.N = L.Cip; d.Hq = 1; d.Wq = (int)rows; d.M = (int)rows;
+  set_out(d, din, 1, (int)rows, ldc);
+  return dmx_gemm_launch(d, st);
+}

@@ -1,0 +1,30 @@
+// Network executors (HiFi-GAN, VAE decoder, U-Net): common base.
+#pragma once
+#include "layers.h"
+#include "../../include/diffmusic_hip.h"
+
+enum { DMX_MODEL_HIFIGAN = 1, DMX_MODEL_VAE = 2, DMX_MODEL_UNET = 3 };
+
+struct Model {
+  int kind = 0;
+  ParamStore ps;
+  Arena arena;
+  bool finalized = false;
+  bool dry = false;  // dry run: only workspace accounting, no launches
+  virtual ~Model() { ps.free_all(); }
+  virtual int finalize(hipStream_t st) = 0;
+};
+struct dmx_model { Model* impl; };
+
+// launch unless dry-running
+#define RUN(expr) do { if (!dry) { int rc_ = (expr); if (rc_ != DMX_OK) return rc_; } } while (0)
+#define CHECK_WS(name) do { if (arena.overflow) { dmx_set_error(name " workspace too small: need %zu bytes", arena.peak); return DMX_ERR_WORKSPACE; } } while (0)
+
+Model* dmx_make_hifigan(const dmx_hifigan_config* c);
+int dmx_hifigan_out_len_impl(Model* m, int T);
+int dmx_hifigan_fwd_impl(Model* m, const act_t* mel, float* wav, int B, int T, void* ws, size_t wsb, hipStream_t st);
+int dmx_hifigan_bwd_impl(Model* m, const float* dwav, act_t* dmel, hipStream_t st);
+size_t dmx_hifigan_ws_impl(Model* m, int B, int T);
+
+Model* dmx_make_vae(const dmx_vae_config* c);
+Model* dmx_make_unet(const dmx_unet_config* c);

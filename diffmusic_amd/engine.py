@@ -1,0 +1,133 @@
+"""Python handles over the native network executors (HiFi-GAN, VAE decoder, U-Net).
+
+Only plumbing lives here: device buffers come from torch (caching allocator), launches go to the
+C ABI on torch's current HIP stream."""
+import ctypes as C
+import torch
+from . import _lib as L
+from .weights import synth_state_dict
+
+HIFIGAN_DEFAULT = dict(model_in_dim=64, upsample_initial_channel=1024, upsample_rates=[5, 4, 2, 2, 2],
+                       upsample_kernel_sizes=[16, 16, 8, 4, 4], resblock_kernel_sizes=[3, 7, 11],
+                       resblock_dilation_sizes=[[1, 3, 5]] * 3, leaky_relu_slope=0.1, sampling_rate=16000)
+VAE_DEFAULT = dict(latent_channels=8, out_channels=1, block_out_channels=[128, 256, 512], layers_per_block=2,
+                   norm_num_groups=32, scaling_factor=0.9227914214134216, eps=1e-6)
+UNET_MUSICLDM_DEFAULT = dict(in_channels=8, out_channels=8, block_out_channels=[128, 256, 384, 640],
+                             layers_per_block=2, attention_heads=8, norm_num_groups=32,
+                             down_attn=[0, 1, 1, 1], up_attn=[1, 1, 1, 0], class_embed_dim=512)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _fill(arr, vals):
+    for i, v in enumerate(vals):
+        arr[i] = int(v)
+
+
+class _Engine:
+    kind = "generic"
+
+    def __init__(self, handle, config, device):
+        if not handle:
+            L.check(-1, "model create")
+        self._h = C.c_void_p(handle)
+        self.cfg = dict(config)
+        self.device = torch.device(device)
+        self._ws = {}
+        self._finalized = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().dmx_model_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def param_specs(self):
+        lib = L.lib()
+        out = []
+        for i in range(lib.dmx_model_num_params(self._h)):
+            nd = lib.dmx_model_param_ndim(self._h, i)
+            out.append((lib.dmx_model_param_name(self._h, i).decode(),
+                        tuple(lib.dmx_model_param_dim(self._h, i, d) for d in range(nd))))
+        return out
+
+    def _stride_of(self, name):
+        return 1
+
+    def synth_state_dict(self, seed=0):
+        return synth_state_dict(self.param_specs(), seed, self.kind, self._stride_of)
+
+    def load_state_dict(self, sd):
+        lib = L.lib()
+        for name, shape in self.param_specs():
+            if name not in sd:
+                raise KeyError(f"state_dict is missing '{name}'")
+            t = sd[name].detach().to(torch.float32).contiguous().cpu()
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError(f"'{name}': expected shape {shape}, got {tuple(t.shape)}")
+            L.check(lib.dmx_model_load_param(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel()), name)
+        with torch.cuda.device(self.device):
+            L.check(lib.dmx_model_finalize(self._h, _stream()), "finalize")
+            torch.cuda.synchronize()
+        self._finalized = True
+        return self
+
+    def _workspace(self, key, nbytes):
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws.clear()
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+
+class HifiGanEngine(_Engine):
+    """`vocoder(mel)` of the reference (operator.py:126-130) + its input-gradient backward."""
+    kind = "hifigan"
+
+    def __init__(self, config=None, device="cuda"):
+        cfg = dict(HIFIGAN_DEFAULT)
+        cfg.update(config or {})
+        c = L.HifiGanConfig()
+        c.model_in_dim, c.upsample_initial_channel = cfg["model_in_dim"], cfg["upsample_initial_channel"]
+        c.num_upsamples = len(cfg["upsample_rates"])
+        _fill(c.upsample_rates, cfg["upsample_rates"])
+        _fill(c.upsample_kernel_sizes, cfg["upsample_kernel_sizes"])
+        c.num_kernels = len(cfg["resblock_kernel_sizes"])
+        _fill(c.resblock_kernel_sizes, cfg["resblock_kernel_sizes"])
+        c.num_dilations = len(cfg["resblock_dilation_sizes"][0])
+        _fill(c.resblock_dilation_sizes, [d for row in cfg["resblock_dilation_sizes"] for d in row])
+        c.leaky_relu_slope = cfg["leaky_relu_slope"]
+        super().__init__(L.lib().dmx_hifigan_create(C.byref(c)), cfg, device)
+
+    def _stride_of(self, name):
+        return self.cfg["upsample_rates"][int(name.split(".")[1])]
+
+    def out_len(self, frames):
+        return L.lib().dmx_hifigan_out_len(self._h, frames)
+
+    def forward(self, mel):
+        """mel (B, T, model_in_dim) act-dtype cuda -> wav (B, out_len) fp32."""
+        assert mel.dtype == L.act_dtype() and mel.is_cuda and mel.is_contiguous()
+        B, T, _ = mel.shape
+        lib = L.lib()
+        ws = self._workspace(("h", B, T), lib.dmx_hifigan_workspace_bytes(self._h, B, T))
+        wav = torch.empty(B, self.out_len(T), dtype=torch.float32, device=mel.device)
+        L.check(lib.dmx_hifigan_fwd(self._h, _ptr(mel), _ptr(wav), B, T, _ptr(ws), ws.numel(), _stream()), "hifigan_fwd")
+        self._shape = (B, T)
+        return wav
+
+    def backward(self, dwav):
+        B, T = self._shape
+        assert dwav.dtype == torch.float32 and dwav.is_contiguous()
+        dmel = torch.empty(B, T, self.cfg["model_in_dim"], dtype=L.act_dtype(), device=dwav.device)
+        L.check(L.lib().dmx_hifigan_bwd(self._h, _ptr(dwav), _ptr(dmel), _stream()), "hifigan_bwd")
+        return dmel

@@ -1,0 +1,122 @@
+/* diffmusic_hip.h -- C ABI of the MI355X-native DiffMusic hot-path library (libdiffmusic_hip.so).
+ *
+ * The reference (jwliao1209/DiffMusic) is pure Python and has no FFI layer; its boundary for this
+ * path is three duck-typed protocols: Scheduler.step()
+ * (diffmusic/schedulers/scheduling_dps.py:137-219 and siblings), Pipeline.__call__()
+ * (diffmusic/pipelines/pipeline_musicldm.py:491-799) and BaseOperator
+ * (diffmusic/inverse_problem/operator.py:6-14).  The Python facade in diffmusic_amd/ keeps those
+ * protocols and binds the entry points below with ctypes (INTEGRATION.md shows the stub a
+ * maintainer of the reference would add).  Each entry point cites the reference call site whose
+ * third-party / PyTorch computation it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; tensors are contiguous;
+ *  - `stream` is a hipStream_t passed as void*; calls are stream-ordered, never synchronise and
+ *    never allocate (model creation / parameter loading / finalize excepted);
+ *  - workspaces are caller-owned device buffers; query sizes with the *_workspace_bytes calls;
+ *  - return value 0 = OK, negative = error (dmx_last_error() gives the message);
+ *  - 16-bit activation tensors (`uint16_t*`) are raw fp16 bit patterns (bf16 when the library was
+ *    built with -DDMX_BF16; query dmx_act_dtype()), channels-last.
+ */
+#ifndef DIFFMUSIC_HIP_H
+#define DIFFMUSIC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMX_ABI_VERSION 1
+#define DMX_MAX_STAGES 8
+
+typedef struct dmx_model dmx_model; /* opaque network handle (weights repacked for MFMA) */
+
+/* transformers SpeechT5HifiGanConfig fields used by the vocoder (operator.py:126-130 call site) */
+typedef struct dmx_hifigan_config {
+  int model_in_dim;             /* 64 */
+  int upsample_initial_channel; /* 1024 */
+  int num_upsamples;            /* 5 */
+  int upsample_rates[DMX_MAX_STAGES];
+  int upsample_kernel_sizes[DMX_MAX_STAGES];
+  int num_kernels;              /* 3 */
+  int resblock_kernel_sizes[DMX_MAX_STAGES];
+  int num_dilations;            /* 3 */
+  int resblock_dilation_sizes[DMX_MAX_STAGES * DMX_MAX_STAGES]; /* [kernel][dilation] */
+  float leaky_relu_slope;       /* 0.1 */
+} dmx_hifigan_config;
+
+/* diffusers AutoencoderKL decoder config (scheduling_dps.py:195-197 call site) */
+typedef struct dmx_vae_config {
+  int latent_channels;          /* 8 */
+  int out_channels;             /* 1 */
+  int num_blocks;               /* 3 */
+  int block_out_channels[DMX_MAX_STAGES]; /* 128,256,512 */
+  int layers_per_block;         /* 2 */
+  int norm_num_groups;          /* 32 */
+  float eps;                    /* 1e-6 */
+} dmx_vae_config;
+
+/* diffusers UNet2DConditionModel config as used by MusicLDM (pipeline_musicldm.py:696-703) and,
+ * with cross_attention contexts, AudioLDM2 (plpeline_audioldm2.py:1147-1154) */
+typedef struct dmx_unet_config {
+  int in_channels, out_channels; /* 8, 8 */
+  int num_blocks;                /* 4 */
+  int block_out_channels[DMX_MAX_STAGES];
+  int layers_per_block;          /* 2 */
+  int attention_heads;           /* 8 */
+  int norm_num_groups;           /* 32 */
+  int down_attn[DMX_MAX_STAGES]; /* 0,1,1,1 */
+  int up_attn[DMX_MAX_STAGES];   /* 1,1,1,0 */
+  int class_embed_dim;           /* 512 (simple_projection, concat) ; 0 = none */
+} dmx_unet_config;
+
+int dmx_abi_version(void);
+int dmx_act_dtype(void); /* 1 = fp16 (default build), 0 = bf16 */
+const char* dmx_last_error(void);
+
+/* ---- model lifecycle ------------------------------------------------------------------------ */
+dmx_model* dmx_hifigan_create(const dmx_hifigan_config* cfg);
+dmx_model* dmx_vae_decoder_create(const dmx_vae_config* cfg);
+dmx_model* dmx_unet_create(const dmx_unet_config* cfg);
+void dmx_model_destroy(dmx_model* m);
+int dmx_model_num_params(const dmx_model* m);
+const char* dmx_model_param_name(const dmx_model* m, int i);
+size_t dmx_model_param_numel(const dmx_model* m, int i);
+int dmx_model_param_ndim(const dmx_model* m, int i);
+int dmx_model_param_dim(const dmx_model* m, int i, int d);
+/* copy one fp32 parameter (upstream naming, e.g. "resblocks.3.convs1.0.weight") from host memory */
+int dmx_model_load_param(dmx_model* m, const char* name, const float* data_host, size_t numel);
+/* repack all parameters into the MFMA layouts; fails if any parameter is missing */
+int dmx_model_finalize(dmx_model* m, void* stream);
+
+/* ---- HiFi-GAN vocoder: replaces `vocoder(mel)` (operator.py:126-130) and its autograd backward */
+int dmx_hifigan_out_len(const dmx_model* m, int frames);
+size_t dmx_hifigan_workspace_bytes(dmx_model* m, int batch, int frames);
+/* mel (B, frames, model_in_dim) f16 -> wav (B, out_len) fp32; keeps the backward state in ws */
+int dmx_hifigan_fwd(dmx_model* m, const uint16_t* mel, float* wav, int batch, int frames, void* ws, size_t ws_bytes,
+                    void* stream);
+/* dwav (B, out_len) fp32 -> dmel (B, frames, model_in_dim) f16; ws as left by the forward call */
+int dmx_hifigan_bwd(dmx_model* m, const float* dwav, uint16_t* dmel, void* stream);
+
+/* ---- VAE decoder: replaces `vae.decode(z).sample` (scheduling_dps.py:195-197) + backward ------- */
+size_t dmx_vae_workspace_bytes(dmx_model* m, int batch, int h, int w);
+/* z (B, latent_channels, h, w) fp32 NCHW, multiplied by z_scale -> mel (B, 4h, 4w) f16 (+ fp32 copy if mel_f32) */
+int dmx_vae_decode_fwd(dmx_model* m, const float* z, float z_scale, uint16_t* mel, float* mel_f32, int batch, int h, int w,
+                       int keep_state, void* ws, size_t ws_bytes, void* stream);
+/* dmel (B, 4h, 4w) f16 -> dz (B, latent_channels, h, w) fp32 NCHW, multiplied by z_scale */
+int dmx_vae_decode_bwd(dmx_model* m, const uint16_t* dmel, float z_scale, float* dz, void* stream);
+
+/* ---- U-Net forward: replaces `self.unet(latent_model_input, t, ..., class_labels=...)` -------- */
+size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w);
+/* x (B, in_ch, h, w) fp32 NCHW, t (B) fp32 timesteps, class_labels (B, class_embed_dim) fp32 -> eps (B, out_ch, h, w) fp32 */
+int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h,
+                 int w, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- low-level test hook: one implicit-GEMM launch described by the internal descriptor --------*/
+int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""-m gpu: the implicit-GEMM kernel (through the C ABI test hook dmx_gemm_raw) against torch fp32
+convolutions on the same bf16-rounded operands."""
+import ctypes as C
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _adt():
+    from diffmusic_amd import _lib as L
+    return L.act_dtype()
+
+
+def _desc(L, **kw):
+    d = L.GemmDesc()
+    d.Z = d.Zi = 1
+    d.sy = d.sx = d.osy = d.osx = 1
+    d.alpha = 1.0
+    for k, v in kw.items():
+        if k in ("tdy", "tdx"):
+            for i, t in enumerate(v):
+                getattr(d, k)[i] = t
+        elif isinstance(v, torch.Tensor):
+            setattr(d, k, v.data_ptr())
+        else:
+            setattr(d, k, v)
+    return d
+
+
+def _run(L, d):
+    L.check(L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    torch.cuda.synchronize()
+
+
+def _rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("B,T,Ci,Co,k,dil", [(2, 333, 64, 128, 3, 1), (1, 1000, 32, 32, 11, 5), (3, 257, 128, 64, 7, 3),
+                                             (1, 130, 8, 16, 7, 1), (2, 77, 512, 512, 3, 1)])
+def test_conv1d_dilated(B, T, Ci, Co, k, dil):
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, Ci, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5).to(_adt()).cuda()
+    bias = torch.randn(Co, generator=g).cuda()
+    res = torch.randn(B, T, Co, generator=g).to(_adt()).cuda()
+    pad = (k * dil - dil) // 2
+    wp = w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()
+    out = torch.empty(B, T, Co, dtype=_adt(), device="cuda")
+    out2 = torch.empty_like(out)
+    d = _desc(L, A=x, W=wp, C=out, C2=out2, bias=bias, R=res, M=B * T, N=Co, K=k * Ci, ldw=k * Ci, Hi=1, Wi=T, Ci=Ci, lda=Ci,
+              Hq=1, Wq=T, ntaps=k, Ho=1, Wo=T, ldc=Co, ldr=Co, ldx=Co, ldc2=Co,
+              flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_LRELU2, act_slope=0.1,
+              tdy=[0] * k, tdx=[t * dil - pad for t in range(k)])
+    _run(L, d)
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias, padding=pad, dilation=dil).transpose(1, 2) + res.float()
+    assert _rel(out, ref) < 6e-3
+    assert _rel(out2, F.leaky_relu(ref, 0.1)) < 6e-3
+
+
+def test_conv2d_3x3_and_stride2():
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(1)
+    B, H, W, Ci, Co = 2, 37, 16, 64, 96
+    x = torch.randn(B, H, W, Ci, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(_adt()).cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+    for stride in (1, 2):
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        out = torch.empty(B, Ho, Wo, Co, dtype=_adt(), device="cuda")
+        d = _desc(L, A=x, W=wp, C=out, M=B * Ho * Wo, N=Co, K=9 * Ci, ldw=9 * Ci, Hi=H, Wi=W, Ci=Ci, lda=Ci, Hq=Ho, Wq=Wo,
+                  sy=stride, sx=stride, ntaps=9, Ho=Ho, Wo=Wo, ldc=Co, tdy=[t // 3 - 1 for t in range(9)],
+                  tdx=[t % 3 - 1 for t in range(9)])
+        _run(L, d)
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, stride=stride, padding=1).permute(0, 2, 3, 1)
+        assert _rel(out, ref) < 6e-3, stride
+
+
+def test_batched_nt_gemm_f32_out_and_mask():
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(2)
+    Z, M, N, K = 6, 250, 252, 48
+    a = torch.randn(Z, M, K, generator=g).to(_adt()).cuda()
+    b = torch.randn(Z, N, K, generator=g).to(_adt()).cuda()
+    out = torch.empty(Z, M, N, dtype=torch.float32, device="cuda")
+    d = _desc(L, A=a, W=b, C=out, M=M, N=N, K=K, ldw=K, Hi=1, Wi=M, Ci=K, lda=K, Hq=1, Wq=M, ntaps=1, Ho=1, Wo=M, ldc=N,
+              Z=Z, Zi=3, sAo=3 * M * K, sAi=M * K, sWo=3 * N * K, sWi=N * K, sCo=3 * M * N, sCi=M * N, alpha=0.25,
+              flags=L.EPI_F32OUT, tdy=[0], tdx=[0])
+    _run(L, d)
+    ref = 0.25 * a.float() @ b.float().transpose(1, 2)
+    assert _rel(out, ref) < 1e-5
+    # mask epilogue
+    xm = torch.randn(Z, M, N, generator=g).to(_adt()).cuda()
+    outb = torch.empty(Z, M, N, dtype=_adt(), device="cuda")
+    d.C = outb.data_ptr(); d.X = xm.data_ptr(); d.ldx = N; d.flags = L.EPI_MASK; d.mask_slope = 0.1; d.alpha = 1.0
+    _run(L, d)
+    ref = (a.float() @ b.float().transpose(1, 2)) * torch.where(xm.float() > 0, 1.0, 0.1)
+    assert _rel(outb, ref) < 6e-3
