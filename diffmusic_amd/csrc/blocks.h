@@ -1,0 +1,164 @@
+// 2-D building blocks shared by the VAE decoder and the U-Net executors: GroupNorm, ResnetBlock2D,
+// attention through batched GEMMs.  Semantics follow diffusers 0.31.0 (SURVEY.md section 8c Appendix
+// B2/B3/B6); tensors are channels-last (B, P, C) fp16.
+//
+// Arena discipline: a block first takes its persistent (tape) buffers, then marks the arena, takes
+// temporaries and releases back to the mark.  Launches are stream-ordered, so a released temporary
+// may be handed out again to a later launch without a hazard.
+#pragma once
+#include "models.h"
+
+struct Ctx {           // per-call execution context
+  Arena* arena;
+  hipStream_t st;
+  bool dry;
+  float* gn_partial;   // scratch for GroupNorm partial sums (model-owned)
+};
+#define CRUN(expr) do { if (!cx.dry) { int rc_ = (expr); if (rc_ != DMX_OK) return rc_; } } while (0)
+#define CTRY(expr) do { int rc__ = (expr); if (rc__ != DMX_OK) return rc__; } while (0)
+
+struct GnTape { float* stats = nullptr; float* scale = nullptr; float* shift = nullptr; };
+
+struct GnLayer {
+  GroupNormLayer g;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  void build(ParamStore& ps, const std::string& pre, int C, int G, float eps) { g = make_gn(ps, pre, C, G, eps); }
+  void bind(ParamStore& ps) { gamma = ps.dev(g.g_id); beta = ps.dev(g.b_id); }
+  GnTape alloc(Ctx& cx, int B) const {
+    GnTape t;
+    t.stats = cx.arena->f32((size_t)B * g.G * 2);
+    t.scale = cx.arena->f32((size_t)B * g.C);
+    t.shift = cx.arena->f32((size_t)B * g.C);
+    return t;
+  }
+  int fwd(Ctx& cx, const act_t* x, act_t* y, int B, int P, int silu, const GnTape& t) const {
+    CRUN(dmx_groupnorm_fwd(x, y, gamma, beta, t.stats, t.scale, t.shift, cx.gn_partial, B, P, g.C, g.G, g.eps, silu, cx.st));
+    return DMX_OK;
+  }
+  int bwd(Ctx& cx, const act_t* x, const act_t* dy, const act_t* add, act_t* dx, int B, int P, int silu, const GnTape& t) const {
+    const size_t mk = cx.arena->mark();
+    float* k0 = cx.arena->f32((size_t)B * g.C);
+    float* k1 = cx.arena->f32((size_t)B * g.C);
+    CRUN(dmx_groupnorm_bwd(x, dy, add, dx, t.stats, t.scale, t.shift, k0, k1, cx.gn_partial, B, P, g.C, g.G, silu, cx.st));
+    cx.arena->release(mk);
+    return DMX_OK;
+  }
+};
+
+struct ResnetTape { const act_t* x = nullptr; act_t* h1 = nullptr; GnTape g1, g2; };
+
+struct Resnet2D {
+  int Cin = 0, Cout = 0;
+  GnLayer norm1, norm2;
+  ConvLayer conv1, conv2, shortcut, temb;
+  bool has_shortcut = false, has_temb = false;
+
+  void build(ParamStore& ps, const std::string& pre, int cin, int cout, int temb_ch, int groups, float eps, bool need_bwd) {
+    Cin = cin; Cout = cout;
+    norm1.build(ps, pre + ".norm1", cin, groups, eps);
+    conv1 = make_conv2d(ps, pre + ".conv1", cin, cout, 3, 1, 1, need_bwd);
+    if (temb_ch > 0) { temb = make_linear(ps, pre + ".time_emb_proj", temb_ch, cout, true, false); has_temb = true; }
+    norm2.build(ps, pre + ".norm2", cout, groups, eps);
+    conv2 = make_conv2d(ps, pre + ".conv2", cout, cout, 3, 1, 1, need_bwd);
+    if (cin != cout) { shortcut = make_conv2d(ps, pre + ".conv_shortcut", cin, cout, 1, 1, 0, need_bwd); has_shortcut = true; }
+  }
+  int pack(ParamStore& ps, hipStream_t st) {
+    norm1.bind(ps); norm2.bind(ps);
+    CTRY(pack_layer(ps, conv1, st));
+    CTRY(pack_layer(ps, conv2, st));
+    if (has_shortcut) CTRY(pack_layer(ps, shortcut, st));
+    if (has_temb) CTRY(pack_layer(ps, temb, st));
+    return DMX_OK;
+  }
+  // x (B,H,W,Cin) -> out (B,H,W,Cout) (caller-allocated).  silu_emb (B, temb_ch) fp16, already SiLU'd.
+  // tape != nullptr keeps what backward() needs (persistent arena allocations).
+  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* silu_emb, ResnetTape* tape) const {
+    Arena& A = *cx.arena;
+    const size_t P = (size_t)H * W;
+    ResnetTape t;
+    t.x = x;
+    if (tape) { t.h1 = A.bf(B * P * Cout); t.g1 = norm1.alloc(cx, B); t.g2 = norm2.alloc(cx, B); }
+    const size_t mk = A.mark();
+    if (!tape) { t.h1 = A.bf(B * P * Cout); t.g1 = norm1.alloc(cx, B); t.g2 = norm2.alloc(cx, B); }
+    act_t* n = A.bf(B * P * (Cin > Cout ? Cin : Cout));
+    CTRY(norm1.fwd(cx, x, n, B, (int)P, 1, t.g1));
+    Epi e1;
+    if (has_temb) {
+      float* rb = A.f32((size_t)B * Cout);
+      Epi et; et.flags = EPI_F32OUT;
+      CRUN(linear_fwd(temb, silu_emb, temb.Cip, rb, Cout, B, et, cx.st));
+      e1.flags = EPI_ROWBIAS; e1.rowbias = rb;
+    }
+    CRUN(conv_fwd_2d(conv1, n, t.h1, B, H, W, e1, cx.st));
+    CTRY(norm2.fwd(cx, t.h1, n, B, (int)P, 1, t.g2));
+    Epi e2; e2.flags = EPI_RESID; e2.R = x;
+    if (has_shortcut) {
+      act_t* sc = A.bf(B * P * Cout);
+      Epi es;
+      CRUN(conv_fwd_2d(shortcut, x, sc, B, H, W, es, cx.st));
+      e2.R = sc;
+    }
+    CRUN(conv_fwd_2d(conv2, n, out, B, H, W, e2, cx.st));
+    A.release(mk);
+    if (tape) *tape = t;
+    return DMX_OK;
+  }
+  // dout (B,H,W,Cout) -> dx (B,H,W,Cin) (caller-allocated; may not alias dout)
+  int bwd(Ctx& cx, const act_t* dout, act_t* dx, int B, int H, int W, const ResnetTape& t) const {
+    Arena& A = *cx.arena;
+    const size_t P = (size_t)H * W;
+    const size_t mk = A.mark();
+    act_t* a = A.bf(B * P * Cout);
+    act_t* b = A.bf(B * P * (Cin > Cout ? Cin : Cout));
+    Epi e;
+    CRUN(conv_bwd_2d(conv2, dout, a, B, H, W, e, cx.st));                 // d n2
+    CTRY(norm2.bwd(cx, t.h1, a, nullptr, b, B, (int)P, 1, t.g2));         // d h1 (in b, Cout channels)
+    act_t* c = A.bf(B * P * Cin);
+    CRUN(conv_bwd_2d(conv1, b, c, B, H, W, e, cx.st));                    // d n1
+    const act_t* add = dout;
+    if (has_shortcut) {
+      CRUN(conv_bwd_2d(shortcut, dout, b, B, H, W, e, cx.st));            // reuse b (Cin channels)
+      add = b;
+    }
+    CTRY(norm1.bwd(cx, t.x, c, add, dx, B, (int)P, 1, t.g1));
+    A.release(mk);
+    return DMX_OK;
+  }
+};
+
+// Multi-head attention core on projected q (B,Nq,C), k/v (B,Nk,C) with `heads` heads of dim C/heads:
+// o = softmax(q k^T * scale [+ colbias]) v, all through batched NT GEMMs with materialised scores.
+// P_keep (B*heads, Nq, Nk) fp16 is written to caller memory when backward needs it, else a temp.
+inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* v, act_t* o, int B, int Nq, int Nk, int C,
+                          int heads, act_t* P_keep, const float* colbias) {
+  Arena& A = *cx.arena;
+  const int dh = C / heads, Z = B * heads;
+  const int Nkp = pad8(Nk);           // P / vT rows are padded to a multiple of 8 keys (zero columns)
+  if ((Nk & 3) || (dh & 7)) { dmx_set_error("attention needs Nk %% 4 == 0 and head_dim %% 8 == 0 (Nk=%d, dh=%d)", Nk, dh); return DMX_ERR_SHAPE; }
+  const float scale = 1.0f / sqrtf((float)dh);
+  const size_t mk = A.mark();
+  float* S = A.f32((size_t)Z * Nq * Nk);
+  act_t* Pm = P_keep ? P_keep : A.bf((size_t)Z * Nq * Nkp);
+  act_t* vT = A.bf((size_t)Z * dh * Nkp);
+  GemmBatch gb;
+  gb.Z = Z; gb.Zi = heads;
+  gb.sAo = (long long)Nq * C; gb.sAi = dh;
+  gb.sBo = (long long)Nk * C; gb.sBi = dh;
+  gb.sCo = (long long)heads * Nq * Nk; gb.sCi = (long long)Nq * Nk;
+  Epi e; e.flags = EPI_F32OUT; e.alpha = scale;
+  CRUN(gemm_nt(q, C, k, C, S, Nk, Nq, Nk, dh, e, gb, cx.st));
+  CRUN(dmx_softmax_fwd(S, Pm, colbias, (long long)Z * Nq, Nk, Nk, Nkp, heads * Nq, cx.st));
+  if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
+  // vT[z] (dh, Nkp) = v[b, :, h*dh:(h+1)*dh]^T
+  CRUN(dmx_transpose(v, vT, Nk, dh, C, Nkp, Z, heads, (long long)Nk * C, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
+  GemmBatch g2;
+  g2.Z = Z; g2.Zi = heads;
+  g2.sAo = (long long)heads * Nq * Nkp; g2.sAi = (long long)Nq * Nkp;
+  g2.sBo = (long long)heads * dh * Nkp; g2.sBi = (long long)dh * Nkp;
+  g2.sCo = (long long)Nq * C; g2.sCi = dh;
+  Epi e2;
+  CRUN(gemm_nt(Pm, Nkp, vT, Nkp, o, C, Nq, dh, Nkp, e2, g2, cx.st));
+  A.release(mk);
+  return DMX_OK;
+}

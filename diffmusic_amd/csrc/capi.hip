@@ -68,6 +68,20 @@ int dmx_hifigan_bwd(dmx_model* m, const float* dwav, uint16_t* dmel, void* strea
   return dmx_hifigan_bwd_impl(m->impl, dwav, dmel, ST(stream));
 }
 
+size_t dmx_vae_workspace_bytes(dmx_model* m, int batch, int h, int w) { return dmx_vae_ws_impl(m->impl, batch, h, w); }
+int dmx_vae_decode_fwd(dmx_model* m, const float* z, float z_scale, uint16_t* mel, float* mel_f32, int batch, int h, int w,
+                       int keep_state, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check(m, DMX_MODEL_VAE);
+  if (rc) return rc;
+  if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
+  return dmx_vae_fwd_impl(m->impl, z, z_scale, mel, mel_f32, batch, h, w, keep_state, ws, ws_bytes, ST(stream));
+}
+int dmx_vae_decode_bwd(dmx_model* m, const uint16_t* dmel, float z_scale, float* dz, void* stream) {
+  int rc = check(m, DMX_MODEL_VAE);
+  if (rc) return rc;
+  return dmx_vae_bwd_impl(m->impl, dmel, z_scale, dz, ST(stream));
+}
+
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream) {
   if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
   return dmx_gemm_launch(*reinterpret_cast<const GemmDesc*>(desc), ST(stream));

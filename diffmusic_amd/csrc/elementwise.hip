@@ -249,6 +249,7 @@ __global__ void softmax_kernel(const float* __restrict__ S, act_t* __restrict__ 
   const float inv = 1.f / sum;
   act_t* p = P + row * ldp;
   for (int i = threadIdx.x; i < N; i += blockDim.x) p[i] = f2a(__expf(s[i] + (cb ? cb[i] : 0.f) - mx) * inv);
+  for (int i = N + threadIdx.x; i < ldp && i < N + 8; i += blockDim.x) p[i] = 0;   // zero the key padding (ldp = pad8(N))
 }
 
 // dS = P * (dP - sum_j dP_j P_j) * scale ; P bf16, dP fp32 -> dS bf16
@@ -443,6 +444,18 @@ __global__ void scatter_col_pad8_kernel(const float* __restrict__ v, act_t* __re
   reinterpret_cast<uint4*>(y)[idx] = make_uint4((uint32_t)f2a(v[idx] * scale), 0u, 0u, 0u);
 }
 
+// (rows, ld) fp32 column -> (rows) fp16
+__global__ void gather_col_f32_to_act_kernel(const float* __restrict__ x, act_t* __restrict__ y, long long rows, int ld, int col) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows) y[idx] = f2a(x[idx * ld + col]);
+}
+// (rows) fp16 -> (rows, 8) fp16 with channel 0 = v
+__global__ void pad_col8_act_kernel(const act_t* __restrict__ v, act_t* __restrict__ y, long long rows) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows) return;
+  reinterpret_cast<uint4*>(y)[idx] = make_uint4((uint32_t)v[idx], 0u, 0u, 0u);
+}
+
 inline void gn_geom(int P, int C, int& nt, int& rpb, int& nchunk, int& ppb) {
   const int cpr = C >> 3;
   rpb = cpr >= 256 ? 1 : 256 / cpr;
@@ -587,5 +600,14 @@ int dmx_tanh_bwd_pad8(const float* dwav, const float* wav8, act_t* gz, long long
 }
 int dmx_scatter_col_pad8(const float* v, act_t* y, long long rows, float scale, hipStream_t st) {
   hipLaunchKernelGGL(scatter_col_pad8_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, v, y, rows, scale);
+  return CHECK_LAUNCH();
+}
+
+int dmx_gather_col_f32_to_act(const float* x, act_t* y, long long rows, int ld, int col, hipStream_t st) {
+  hipLaunchKernelGGL(gather_col_f32_to_act_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, x, y, rows, ld, col);
+  return CHECK_LAUNCH();
+}
+int dmx_pad_col8_act(const act_t* v, act_t* y, long long rows, hipStream_t st) {
+  hipLaunchKernelGGL(pad_col8_act_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, v, y, rows);
   return CHECK_LAUNCH();
 }

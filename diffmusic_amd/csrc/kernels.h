@@ -34,6 +34,8 @@ int dmx_extract_col(const act_t* x, float* y, long long rows, int ld, int col, h
 int dmx_gather_col_f32(const float* x, float* y, long long rows, int ld, int col, hipStream_t st);
 int dmx_tanh_bwd_pad8(const float* dwav, const float* wav8, act_t* gz, long long rows, hipStream_t st);
 int dmx_scatter_col_pad8(const float* v, act_t* y, long long rows, float scale, hipStream_t st);
+int dmx_gather_col_f32_to_act(const float* x, act_t* y, long long rows, int ld, int col, hipStream_t st);
+int dmx_pad_col8_act(const act_t* v, act_t* y, long long rows, hipStream_t st);
 int dmx_timestep_embed(const float* t, act_t* y, int B, int dim, hipStream_t st);
 
 // ---- mel.hip (measurement operators + mel transform, fp32)

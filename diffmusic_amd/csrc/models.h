@@ -27,4 +27,8 @@ int dmx_hifigan_bwd_impl(Model* m, const float* dwav, act_t* dmel, hipStream_t s
 size_t dmx_hifigan_ws_impl(Model* m, int B, int T);
 
 Model* dmx_make_vae(const dmx_vae_config* c);
+size_t dmx_vae_ws_impl(Model* m, int B, int h, int w);
+int dmx_vae_fwd_impl(Model* m, const float* z, float zs, act_t* mel, float* mel32, int B, int h, int w, int keep, void* ws, size_t wsb,
+                     hipStream_t st);
+int dmx_vae_bwd_impl(Model* m, const act_t* dmel, float zs, float* dz, hipStream_t st);
 Model* dmx_make_unet(const dmx_unet_config* c);

@@ -1,3 +1,2 @@
 #include "models.h"
-Model* dmx_make_vae(const dmx_vae_config*) { dmx_set_error("vae not built yet"); return nullptr; }
 Model* dmx_make_unet(const dmx_unet_config*) { dmx_set_error("unet not built yet"); return nullptr; }

@@ -131,3 +131,41 @@ class HifiGanEngine(_Engine):
         dmel = torch.empty(B, T, self.cfg["model_in_dim"], dtype=L.act_dtype(), device=dwav.device)
         L.check(L.lib().dmx_hifigan_bwd(self._h, _ptr(dwav), _ptr(dmel), _stream()), "hifigan_bwd")
         return dmel
+
+
+class VaeDecoderEngine(_Engine):
+    """`vae.decode(z).sample` of the reference (scheduling_dps.py:195-197) + input-gradient backward."""
+    kind = "vae"
+
+    def __init__(self, config=None, device="cuda"):
+        cfg = dict(VAE_DEFAULT)
+        cfg.update(config or {})
+        c = L.VaeConfig()
+        c.latent_channels, c.out_channels = cfg["latent_channels"], cfg["out_channels"]
+        c.num_blocks = len(cfg["block_out_channels"])
+        _fill(c.block_out_channels, cfg["block_out_channels"])
+        c.layers_per_block, c.norm_num_groups, c.eps = cfg["layers_per_block"], cfg["norm_num_groups"], cfg["eps"]
+        super().__init__(L.lib().dmx_vae_decoder_create(C.byref(c)), cfg, device)
+        self.scale_factor = 2 ** (c.num_blocks - 1)
+        self.scaling_factor = cfg["scaling_factor"]
+
+    def decode(self, z, z_scale=1.0, keep_state=True, want_f32=False):
+        """z (B, latent, h, w) fp32 NCHW -> mel (B, H, W) act dtype [, fp32 copy]."""
+        assert z.dtype == torch.float32 and z.is_cuda and z.is_contiguous()
+        B, _, h, w = z.shape
+        lib = L.lib()
+        ws = self._workspace(("v", B, h, w), lib.dmx_vae_workspace_bytes(self._h, B, h, w))
+        s = self.scale_factor
+        mel = torch.empty(B, h * s, w * s, dtype=L.act_dtype(), device=z.device)
+        mel32 = torch.empty(B, h * s, w * s, dtype=torch.float32, device=z.device) if want_f32 else None
+        L.check(lib.dmx_vae_decode_fwd(self._h, _ptr(z), float(z_scale), _ptr(mel), _ptr(mel32), B, h, w, int(keep_state),
+                                       _ptr(ws), ws.numel(), _stream()), "vae_decode_fwd")
+        self._shape = (B, h, w)
+        return (mel, mel32) if want_f32 else mel
+
+    def backward(self, dmel, z_scale=1.0):
+        B, h, w = self._shape
+        assert dmel.dtype == L.act_dtype() and dmel.is_contiguous()
+        dz = torch.empty(B, self.cfg["latent_channels"], h, w, dtype=torch.float32, device=dmel.device)
+        L.check(L.lib().dmx_vae_decode_bwd(self._h, _ptr(dmel), float(z_scale), _ptr(dz), _stream()), "vae_decode_bwd")
+        return dz
