@@ -82,6 +82,15 @@ int dmx_vae_decode_bwd(dmx_model* m, const uint16_t* dmel, float z_scale, float*
   return dmx_vae_bwd_impl(m->impl, dmel, z_scale, dz, ST(stream));
 }
 
+size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w) { return dmx_unet_ws_impl(m->impl, batch, h, w); }
+int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h, int w,
+                 void* ws, size_t ws_bytes, void* stream) {
+  int rc = check(m, DMX_MODEL_UNET);
+  if (rc) return rc;
+  if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
+  return dmx_unet_fwd_impl(m->impl, x, t, class_labels, eps, batch, h, w, ws, ws_bytes, ST(stream));
+}
+
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream) {
   if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
   return dmx_gemm_launch(*reinterpret_cast<const GemmDesc*>(desc), ST(stream));

@@ -1,0 +1,341 @@
+// UNet2DConditionModel forward (inference only; the guidance gradient never enters the U-Net because
+// every in-scope scheduler detaches `sample` and treats eps as a constant, scheduling_dps.py:165).
+// diffusers 0.31.0 semantics as configured for MusicLDM:
+// simple_projection class embedding concatenated to the time embedding, encoder_hidden_states=None
+// so both attention layers of a transformer block are self-attention, conv proj_in/proj_out, GEGLU.
+// Replaces `self.unet(latent_model_input, t, encoder_hidden_states=None, class_labels=prompt_embeds)`
+// (diffmusic/pipelines/pipeline_musicldm.py:696-703).
+#include "blocks.h"
+
+struct LnParams {
+  int g_id = -1, b_id = -1;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  void build(ParamStore& ps, const std::string& pre, int C) { g_id = ps.add(pre + ".weight", {C}); b_id = ps.add(pre + ".bias", {C}); }
+  void bind(ParamStore& ps) { gamma = ps.dev(g_id); beta = ps.dev(b_id); }
+};
+
+struct AttnLayer {
+  ConvLayer to_q, to_k, to_v, to_out;
+  int heads = 1, C = 0;
+  void build(ParamStore& ps, const std::string& pre, int dim, int cross_dim, int heads_) {
+    heads = heads_; C = dim;
+    to_q = make_linear(ps, pre + ".to_q", dim, dim, false, false);
+    to_k = make_linear(ps, pre + ".to_k", cross_dim, dim, false, false);
+    to_v = make_linear(ps, pre + ".to_v", cross_dim, dim, false, false);
+    to_out = make_linear(ps, pre + ".to_out.0", dim, dim, true, false);
+  }
+  int pack(ParamStore& ps, hipStream_t st) {
+    CTRY(pack_layer(ps, to_q, st)); CTRY(pack_layer(ps, to_k, st));
+    CTRY(pack_layer(ps, to_v, st)); CTRY(pack_layer(ps, to_out, st));
+    return DMX_OK;
+  }
+  // hres += to_out(attn(l, ctx)) ; l (B,N,C) normalised input, ctx (B,Nc,Cc) or nullptr (self)
+  int fwd(Ctx& cx, const act_t* l, const act_t* ctx, int Nc, act_t* hres, int B, int N, const float* colbias) const {
+    Arena& A = *cx.arena;
+    const size_t mk = A.mark();
+    const act_t* kv_in = ctx ? ctx : l;
+    const int Nk = ctx ? Nc : N;
+    act_t* q = A.bf((size_t)B * N * C);
+    act_t* k = A.bf((size_t)B * Nk * C);
+    act_t* v = A.bf((size_t)B * Nk * C);
+    act_t* o = A.bf((size_t)B * N * C);
+    Epi e;
+    CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
+    CRUN(linear_fwd(to_k, kv_in, to_k.Cip, k, C, (long long)B * Nk, e, cx.st));
+    CRUN(linear_fwd(to_v, kv_in, to_v.Cip, v, C, (long long)B * Nk, e, cx.st));
+    CTRY(attention_core(cx, q, k, v, o, B, N, Nk, C, heads, nullptr, colbias));
+    Epi er; er.flags = EPI_RESID; er.R = hres;
+    CRUN(linear_fwd(to_out, o, C, hres, C, (long long)B * N, er, cx.st));
+    A.release(mk);
+    return DMX_OK;
+  }
+};
+
+struct Transformer2D {
+  int C = 0;
+  GnLayer norm;
+  ConvLayer proj_in, proj_out, ff1, ff2;
+  LnParams ln1, ln2, ln3;
+  AttnLayer attn1, attn2;
+  void build(ParamStore& ps, const std::string& pre, int ch, int heads, int cross_dim, int groups) {
+    C = ch;
+    norm.build(ps, pre + ".norm", ch, groups, 1e-6f);
+    proj_in = make_conv2d(ps, pre + ".proj_in", ch, ch, 1, 1, 0, false);
+    const std::string tb = pre + ".transformer_blocks.0";
+    ln1.build(ps, tb + ".norm1", ch);
+    attn1.build(ps, tb + ".attn1", ch, ch, heads);
+    ln2.build(ps, tb + ".norm2", ch);
+    attn2.build(ps, tb + ".attn2", ch, cross_dim, heads);
+    ln3.build(ps, tb + ".norm3", ch);
+    ff1 = make_linear(ps, tb + ".ff.net.0.proj", ch, ch * 8, true, false);
+    ff2 = make_linear(ps, tb + ".ff.net.2", ch * 4, ch, true, false);
+    proj_out = make_conv2d(ps, pre + ".proj_out", ch, ch, 1, 1, 0, false);
+  }
+  int pack(ParamStore& ps, hipStream_t st) {
+    norm.bind(ps); ln1.bind(ps); ln2.bind(ps); ln3.bind(ps);
+    CTRY(pack_layer(ps, proj_in, st)); CTRY(pack_layer(ps, proj_out, st));
+    CTRY(pack_layer(ps, ff1, st)); CTRY(pack_layer(ps, ff2, st));
+    CTRY(attn1.pack(ps, st)); CTRY(attn2.pack(ps, st));
+    return DMX_OK;
+  }
+  // x (B,H,W,C) -> out (B,H,W,C); out may not alias x
+  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W) const {
+    Arena& A = *cx.arena;
+    const int N = H * W;
+    const size_t mk = A.mark();
+    GnTape gt = norm.alloc(cx, B);
+    act_t* n = A.bf((size_t)B * N * C);
+    act_t* hbuf = A.bf((size_t)B * N * C);
+    act_t* l = A.bf((size_t)B * N * C);
+    CTRY(norm.fwd(cx, x, n, B, N, 0, gt));
+    Epi e;
+    CRUN(conv_fwd_2d(proj_in, n, hbuf, B, H, W, e, cx.st));
+    CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
+    CTRY(attn1.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));
+    CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
+    CTRY(attn2.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));     // encoder_hidden_states=None -> self-attention
+    CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
+    {
+      const size_t mk2 = A.mark();
+      act_t* f = A.bf((size_t)B * N * C * 8);
+      act_t* gg = A.bf((size_t)B * N * C * 4);
+      CRUN(linear_fwd(ff1, l, C, f, C * 8, (long long)B * N, e, cx.st));
+      CRUN(dmx_geglu(f, gg, (long long)B * N, C * 4, cx.st));
+      Epi er; er.flags = EPI_RESID; er.R = hbuf;
+      CRUN(linear_fwd(ff2, gg, C * 4, hbuf, C, (long long)B * N, er, cx.st));
+      A.release(mk2);
+    }
+    Epi eo; eo.flags = EPI_RESID; eo.R = x;
+    CRUN(conv_fwd_2d(proj_out, hbuf, out, B, H, W, eo, cx.st));
+    A.release(mk);
+    return DMX_OK;
+  }
+};
+
+struct UNet : Model {
+  dmx_unet_config cfg;
+  ConvLayer time1, time2, class_emb, conv_in, conv_out;
+  GnLayer norm_out;
+  struct Block {
+    std::vector<Resnet2D> res;
+    std::vector<Transformer2D> attn;
+    bool has_attn = false, has_sampler = false;
+    ConvLayer sampler;
+    int ch = 0;
+  };
+  std::vector<Block> down, up;
+  Resnet2D mid_r0, mid_r1;
+  Transformer2D mid_attn;
+  float* gn_partial = nullptr;
+  int temb_ch = 0, tdim = 0;
+
+  explicit UNet(const dmx_unet_config& c) : cfg(c) {
+    kind = DMX_MODEL_UNET;
+    const int nb = c.num_blocks, G = c.norm_num_groups, hd = c.attention_heads;
+    const int* boc = c.block_out_channels;
+    tdim = boc[0] * 4;
+    temb_ch = c.class_embed_dim > 0 ? tdim * 2 : tdim;
+    time1 = make_linear(ps, "time_embedding.linear_1", boc[0], tdim, true, false);
+    time2 = make_linear(ps, "time_embedding.linear_2", tdim, tdim, true, false);
+    if (c.class_embed_dim > 0) class_emb = make_linear(ps, "class_embedding", c.class_embed_dim, tdim, true, false);
+    conv_in = make_conv2d(ps, "conv_in", c.in_channels, boc[0], 3, 1, 1, false);
+    int out = boc[0];
+    for (int i = 0; i < nb; ++i) {
+      const int cin = out;
+      out = boc[i];
+      Block b;
+      b.ch = out; b.has_attn = c.down_attn[i] != 0; b.has_sampler = i != nb - 1;
+      const std::string pre = "down_blocks." + std::to_string(i);
+      b.res.resize(c.layers_per_block);
+      if (b.has_attn) b.attn.resize(c.layers_per_block);
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        b.res[j].build(ps, pre + ".resnets." + std::to_string(j), j == 0 ? cin : out, out, temb_ch, G, 1e-5f, false);
+        if (b.has_attn) b.attn[j].build(ps, pre + ".attentions." + std::to_string(j), out, hd, out, G);
+      }
+      if (b.has_sampler) b.sampler = make_conv2d(ps, pre + ".downsamplers.0.conv", out, out, 3, 2, 1, false);
+      down.push_back(b);
+    }
+    const int cm = boc[nb - 1];
+    mid_r0.build(ps, "mid_block.resnets.0", cm, cm, temb_ch, G, 1e-5f, false);
+    mid_attn.build(ps, "mid_block.attentions.0", cm, hd, cm, G);
+    mid_r1.build(ps, "mid_block.resnets.1", cm, cm, temb_ch, G, 1e-5f, false);
+    out = boc[nb - 1];
+    for (int i = 0; i < nb; ++i) {
+      const int prev = out;
+      out = boc[nb - 1 - i];
+      const int cin = boc[nb - 1 - (i + 1 < nb ? i + 1 : nb - 1)];
+      Block b;
+      b.ch = out; b.has_attn = c.up_attn[i] != 0; b.has_sampler = i != nb - 1;
+      const std::string pre = "up_blocks." + std::to_string(i);
+      const int n = c.layers_per_block + 1;
+      b.res.resize(n);
+      if (b.has_attn) b.attn.resize(n);
+      for (int j = 0; j < n; ++j) {
+        const int skip = j == n - 1 ? cin : out;
+        const int rin = j == 0 ? prev : out;
+        b.res[j].build(ps, pre + ".resnets." + std::to_string(j), rin + skip, out, temb_ch, G, 1e-5f, false);
+        if (b.has_attn) b.attn[j].build(ps, pre + ".attentions." + std::to_string(j), out, hd, out, G);
+      }
+      if (b.has_sampler) b.sampler = make_conv2d(ps, pre + ".upsamplers.0.conv", out, out, 3, 1, 1, false);
+      up.push_back(b);
+    }
+    norm_out.build(ps, "conv_norm_out", boc[0], G, 1e-5f);
+    conv_out = make_conv2d(ps, "conv_out", boc[0], c.out_channels, 3, 1, 1, false);
+    gn_partial = (float*)ps.dalloc(dmx_gn_scratch_floats(64, 2048, G) * sizeof(float));
+  }
+
+  int finalize(hipStream_t st) override {
+    CTRY(pack_layer(ps, time1, st)); CTRY(pack_layer(ps, time2, st));
+    if (cfg.class_embed_dim > 0) CTRY(pack_layer(ps, class_emb, st));
+    CTRY(pack_layer(ps, conv_in, st)); CTRY(pack_layer(ps, conv_out, st));
+    norm_out.bind(ps);
+    for (auto* blocks : {&down, &up})
+      for (auto& b : *blocks) {
+        for (auto& r : b.res) CTRY(r.pack(ps, st));
+        for (auto& a : b.attn) CTRY(a.pack(ps, st));
+        if (b.has_sampler) CTRY(pack_layer(ps, b.sampler, st));
+      }
+    CTRY(mid_r0.pack(ps, st)); CTRY(mid_attn.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
+    return DMX_OK;
+  }
+
+  struct Skip { act_t* p; int H, W, C; };
+
+  int forward(const float* x, const float* t, const float* cls, float* eps, int B, int H0, int W0, void* ws, size_t wsb, hipStream_t st) {
+    if (B > 64) { dmx_set_error("unet: batch > 64 unsupported"); return DMX_ERR_SHAPE; }
+    dry = (ws == nullptr);
+    arena.reset(ws, dry ? (size_t)-1 : wsb);
+    Ctx cx{&arena, st, dry, gn_partial};
+    Arena& A = arena;
+    const int nb = cfg.num_blocks;
+    const int* boc = cfg.block_out_channels;
+    Epi e;
+    // ---- embeddings: silu([time_emb | class_emb])
+    act_t* semb = A.bf((size_t)B * temb_ch);
+    {
+      const size_t mk = A.mark();
+      act_t* te = A.bf((size_t)B * boc[0]);
+      act_t* t1 = A.bf((size_t)B * tdim);
+      act_t* emb = A.bf((size_t)B * temb_ch);
+      CRUN(dmx_timestep_embed(t, te, B, boc[0], st));
+      CRUN(linear_fwd(time1, te, boc[0], t1, tdim, B, e, st));
+      CRUN(dmx_silu(t1, t1, (long long)B * tdim, st));
+      CRUN(linear_fwd(time2, t1, tdim, emb, temb_ch, B, e, st));
+      if (cfg.class_embed_dim > 0) {
+        act_t* c16 = A.bf((size_t)B * cfg.class_embed_dim);
+        CRUN(dmx_f32_to_bf16(cls, c16, (long long)B * cfg.class_embed_dim, 1.f, st));
+        CRUN(linear_fwd(class_emb, c16, cfg.class_embed_dim, emb + tdim, temb_ch, B, e, st));
+      }
+      CRUN(dmx_silu(emb, semb, (long long)B * temb_ch, st));
+      A.release(mk);
+    }
+    // ---- input conv
+    int H = H0, W = W0;
+    std::vector<Skip> skips;
+    const int Cin_p = conv_in.Cip;
+    act_t* cur = A.bf((size_t)B * H * W * boc[0]);
+    {
+      const size_t mk = A.mark();
+      act_t* x16 = A.bf((size_t)B * H * W * Cin_p);
+      CRUN(dmx_nchw_f32_to_nhwc_bf16(x, x16, B, cfg.in_channels, H * W, Cin_p, 1.f, st));
+      CRUN(conv_fwd_2d(conv_in, x16, cur, B, H, W, e, st));
+      A.release(mk);
+    }
+    skips.push_back({cur, H, W, boc[0]});
+    // ---- down
+    for (int i = 0; i < nb; ++i) {
+      Block& b = down[i];
+      for (size_t j = 0; j < b.res.size(); ++j) {
+        act_t* y = A.bf((size_t)B * H * W * b.ch);
+        if (b.has_attn) {
+          act_t* y2 = A.bf((size_t)B * H * W * b.ch);   // resnet output (transient but simpler to keep)
+          CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr));
+          CTRY(b.attn[j].fwd(cx, y2, y, B, H, W));
+        } else {
+          CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr));
+        }
+        cur = y;
+        skips.push_back({cur, H, W, b.ch});
+      }
+      if (b.has_sampler) {
+        const int H2 = (H + 2 - 3) / 2 + 1, W2 = (W + 2 - 3) / 2 + 1;
+        act_t* y = A.bf((size_t)B * H2 * W2 * b.ch);
+        CRUN(conv_fwd_2d(b.sampler, cur, y, B, H, W, e, st));
+        cur = y; H = H2; W = W2;
+        skips.push_back({cur, H, W, b.ch});
+      }
+    }
+    // ---- mid
+    {
+      const int cm = boc[nb - 1];
+      act_t* y0 = A.bf((size_t)B * H * W * cm);
+      act_t* y1 = A.bf((size_t)B * H * W * cm);
+      act_t* y2 = A.bf((size_t)B * H * W * cm);
+      CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr));
+      CTRY(mid_attn.fwd(cx, y0, y1, B, H, W));
+      CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr));
+      cur = y2;
+    }
+    // ---- up
+    int curC = boc[nb - 1];
+    for (int i = 0; i < nb; ++i) {
+      Block& b = up[i];
+      for (size_t j = 0; j < b.res.size(); ++j) {
+        const Skip s = skips.back();
+        skips.pop_back();
+        if (s.H != H || s.W != W) { dmx_set_error("unet skip shape mismatch"); return DMX_ERR_STATE; }
+        const int cc = curC + s.C;
+        act_t* y = A.bf((size_t)B * H * W * b.ch);
+        act_t* y2 = b.has_attn ? A.bf((size_t)B * H * W * b.ch) : nullptr;
+        const size_t mk = A.mark();
+        act_t* cat = A.bf((size_t)B * H * W * cc);
+        CRUN(dmx_copy_channels(cur, cat, (long long)B * H * W, curC, curC, cc, 0, 0, st));
+        CRUN(dmx_copy_channels(s.p, cat, (long long)B * H * W, s.C, s.C, cc, 0, curC, st));
+        if (b.has_attn) {
+          CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr));
+          CTRY(b.attn[j].fwd(cx, y2, y, B, H, W));
+        } else {
+          CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr));
+        }
+        A.release(mk);
+        cur = y; curC = b.ch;
+      }
+      if (b.has_sampler) {
+        const Skip nxt = skips.back();                 // upsample to the matching skip's size (forward_upsample_size)
+        const int H2 = nxt.H, W2 = nxt.W;
+        act_t* y = A.bf((size_t)B * H2 * W2 * b.ch);
+        const size_t mk = A.mark();
+        act_t* u = A.bf((size_t)B * H2 * W2 * b.ch);
+        CRUN(dmx_upsample_nearest(cur, u, B, H, W, H2, W2, b.ch, st));
+        CRUN(conv_fwd_2d(b.sampler, u, y, B, H2, W2, e, st));
+        A.release(mk);
+        cur = y; H = H2; W = W2;
+      }
+    }
+    // ---- out
+    {
+      GnTape gt = norm_out.alloc(cx, B);
+      act_t* n = A.bf((size_t)B * H * W * boc[0]);
+      act_t* o = A.bf((size_t)B * H * W * conv_out.Cop);
+      CTRY(norm_out.fwd(cx, cur, n, B, H * W, 1, gt));
+      CRUN(conv_fwd_2d(conv_out, n, o, B, H, W, e, st));
+      CRUN(dmx_nhwc_bf16_to_nchw_f32(o, eps, B, cfg.out_channels, H * W, conv_out.Cop, 1.f, st));
+    }
+    CHECK_WS("unet");
+    return DMX_OK;
+  }
+};
+
+Model* dmx_make_unet(const dmx_unet_config* c) { return new UNet(*c); }
+size_t dmx_unet_ws_impl(Model* m, int B, int h, int w) {
+  UNet* u = static_cast<UNet*>(m);
+  u->arena.peak = 0;
+  u->forward(nullptr, nullptr, nullptr, nullptr, B, h, w, nullptr, 0, nullptr);
+  u->dry = false;
+  return u->arena.peak + 256;
+}
+int dmx_unet_fwd_impl(Model* m, const float* x, const float* t, const float* cls, float* eps, int B, int h, int w, void* ws, size_t wsb,
+                      hipStream_t st) {
+  return static_cast<UNet*>(m)->forward(x, t, cls, eps, B, h, w, ws, wsb, st);
+}

@@ -169,3 +169,36 @@ class VaeDecoderEngine(_Engine):
         dz = torch.empty(B, self.cfg["latent_channels"], h, w, dtype=torch.float32, device=dmel.device)
         L.check(L.lib().dmx_vae_decode_bwd(self._h, _ptr(dmel), float(z_scale), _ptr(dz), _stream()), "vae_decode_bwd")
         return dz
+
+
+class UNetEngine(_Engine):
+    """`self.unet(latent_model_input, t, encoder_hidden_states=None, class_labels=prompt_embeds)[0]`
+    of the reference (pipeline_musicldm.py:696-703), forward only."""
+    kind = "unet"
+
+    def __init__(self, config=None, device="cuda"):
+        cfg = dict(UNET_MUSICLDM_DEFAULT)
+        cfg.update(config or {})
+        c = L.UNetConfig()
+        c.in_channels, c.out_channels = cfg["in_channels"], cfg["out_channels"]
+        c.num_blocks = len(cfg["block_out_channels"])
+        _fill(c.block_out_channels, cfg["block_out_channels"])
+        c.layers_per_block, c.attention_heads = cfg["layers_per_block"], cfg["attention_heads"]
+        c.norm_num_groups = cfg["norm_num_groups"]
+        _fill(c.down_attn, cfg["down_attn"])
+        _fill(c.up_attn, cfg["up_attn"])
+        c.class_embed_dim = cfg["class_embed_dim"]
+        super().__init__(L.lib().dmx_unet_create(C.byref(c)), cfg, device)
+
+    def forward(self, x, t, class_labels):
+        """x (B, C, h, w) fp32, t (B,) fp32, class_labels (B, class_embed_dim) fp32 -> eps fp32 like x."""
+        assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
+        B, _, h, w = x.shape
+        t = t.to(device=x.device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        class_labels = class_labels.to(device=x.device, dtype=torch.float32).contiguous()
+        lib = L.lib()
+        ws = self._workspace(("u", B, h, w), lib.dmx_unet_workspace_bytes(self._h, B, h, w))
+        eps = torch.empty(B, self.cfg["out_channels"], h, w, dtype=torch.float32, device=x.device)
+        L.check(lib.dmx_unet_fwd(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(eps), B, h, w, _ptr(ws), ws.numel(),
+                                 _stream()), "unet_fwd")
+        return eps
