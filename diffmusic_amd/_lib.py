@@ -81,6 +81,22 @@ _SIGS = {
     "dmx_unet_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dmx_audio_destroy": (None, [C.c_void_p]),
+    "dmx_audio_num_frames": (C.c_int, [C.c_void_p, C.c_int]),
+    "dmx_audio_state_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "dmx_audio_transform_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dmx_audio_transform_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "dmx_audio_stft_mag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dmx_audio_melscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dmx_mask_apply": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dmx_l2_loss": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_grad_normalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_sched_pred_x0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_sched_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_sched_step": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -38,10 +38,27 @@ int dmx_gather_col_f32_to_act(const float* x, act_t* y, long long rows, int ld, 
 int dmx_pad_col8_act(const act_t* v, act_t* y, long long rows, hipStream_t st);
 int dmx_timestep_embed(const float* t, act_t* y, int B, int dim, hipStream_t st);
 
-// ---- mel.hip (measurement operators + mel transform, fp32)
-int dmx_logmel_fwd(const float* wav, const float* fb, float* mel, float* power_ws, int B, int L, int n_mels, int to_db,
-                   float clamp_lo, float clamp_hi, int window_hann, hipStream_t st);
-int dmx_logmel_bwd(const float* wav, const float* fb, const float* dmel, float* dwav, int B, int L, int n_mels, int to_db,
-                   float clamp_lo, float clamp_hi, int window_hann, hipStream_t st);
+// ---- mel.hip (STFT / mel measurement path, fp32)
+int dmx_stft_tables(float* table, float* tableT, int n_fft, int bins, int Npad, int Kpad, int hann, hipStream_t st);
+int dmx_stft_fwd(const float* wav, long long wav_stride, const float* table, float* X, int B, int L, int T, int n_fft, int hop, int Npad,
+                 hipStream_t st);
+int dmx_stft_bwd_frames(const float* Y, const float* tableT, float* dframe, int M, int n_fft, int Kpad, hipStream_t st);
+int dmx_mel_fwd(const float* X, const float* fb, float* mel_lin, float* mel_out, int rows, int ldx, int bins, int n_mels, int power2,
+                int to_db, float lo, float hi, hipStream_t st);
+int dmx_mel_bwd(const float* X, const float* fb, const float* mel_lin, const float* dmel, float* Y, int rows, int ldx, int ldy, int bins,
+                int n_mels, int power2, int to_db, float lo, float hi, hipStream_t st);
+int dmx_stft_mag(const float* X, float* mag, int B, int T, int bins, int ldx, hipStream_t st);
+int dmx_overlap_add(const float* dframe, float* dwav, long long out_stride, int B, int T, int L, int n_fft, int hop, int accumulate,
+                    hipStream_t st);
+int dmx_l2_loss_grad(const float* ref, const float* pred, float* loss, float* dpred, int B, long long n, long long ref_stride, float gscale,
+                     hipStream_t st);
+int dmx_mask_mul(const float* x, long long xs, const float* mask, float* y, long long ys, int B, int L, int Ly, hipStream_t st);
+int dmx_melscale(const float* mag, const float* fb, float* mel, int B, int T, int bins, int n_mels, float lo, float hi, hipStream_t st);
+int dmx_absmax_normalize(float* x, float* inv_scale, int B, long long n, float target, hipStream_t st);
 
 // ---- sched.hip
+int dmx_pred_x0(const float* x, const float* eps, float* x0, long long n, float sqrt_a, float sqrt_1ma, hipStream_t st);
+int dmx_cfg_combine(const float* eps2, float* out, long long n, float scale, hipStream_t st);
+int dmx_sched_update(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
+                     const float* noise, float* prev, float* x0_out, float* grad_out, int B, int n, float alpha_t, float alpha_prev,
+                     float sigma, float rate, float eps_small, int global_norm, hipStream_t st);

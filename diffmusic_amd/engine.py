@@ -111,8 +111,17 @@ class HifiGanEngine(_Engine):
     def _stride_of(self, name):
         return self.cfg["upsample_rates"][int(name.split(".")[1])]
 
+    @property
+    def config(self):
+        from types import SimpleNamespace
+        return SimpleNamespace(**self.cfg)
+
     def out_len(self, frames):
         return L.lib().dmx_hifigan_out_len(self._h, frames)
+
+    def __call__(self, mel):
+        """`vocoder(mel_spectrogram)` of the reference: (B, T, model_in_dim) any float dtype -> (B, samples) fp32."""
+        return self.forward(mel.to(device=self.device, dtype=L.act_dtype()).contiguous())
 
     def forward(self, mel):
         """mel (B, T, model_in_dim) act-dtype cuda -> wav (B, out_len) fp32."""
@@ -149,7 +158,18 @@ class VaeDecoderEngine(_Engine):
         self.scale_factor = 2 ** (c.num_blocks - 1)
         self.scaling_factor = cfg["scaling_factor"]
 
-    def decode(self, z, z_scale=1.0, keep_state=True, want_f32=False):
+    @property
+    def config(self):
+        from types import SimpleNamespace
+        return SimpleNamespace(**self.cfg)
+
+    def decode(self, z):
+        """diffusers-shaped `vae.decode(z).sample`: (B, latent, h, w) -> (B, 1, 4h, 4w) fp32 (no backward state)."""
+        from types import SimpleNamespace
+        _, m32 = self.decode_hip(z.to(device=self.device, dtype=torch.float32).contiguous(), 1.0, keep_state=False, want_f32=True)
+        return SimpleNamespace(sample=m32.unsqueeze(1))
+
+    def decode_hip(self, z, z_scale=1.0, keep_state=True, want_f32=False):
         """z (B, latent, h, w) fp32 NCHW -> mel (B, H, W) act dtype [, fp32 copy]."""
         assert z.dtype == torch.float32 and z.is_cuda and z.is_contiguous()
         B, _, h, w = z.shape

@@ -1,0 +1,295 @@
+"""Measurement operators A(.) with the reference's BaseOperator protocol
+(diffmusic/inverse_problem/operator.py:6-14): forward / transform / inverse_transform, same
+constructor signatures as run.py:164-212 uses.  All arithmetic runs in the HIP library
+(csrc/mel.hip) on the input tensor's device -- the reference's hard-coded .to("cuda")
+(operator.py:33,83,149,191,226) is not reproduced.
+
+Extension used by the guided schedulers (no torch.autograd on the hot path):
+`guidance(wav, L, measurement, supervised_space)` returns the per-clip loss ||y - A(wav)|| (in the
+chosen space) and its gradient with respect to the vocoder output, computed by hand-written
+backward kernels (the reference gets the same quantity from torch.autograd.grad,
+scheduling_dps.py:202-212)."""
+import ctypes as C
+import math
+import numpy as np
+import torch
+
+from .. import _lib as L
+from . import dsp
+
+_NEG, _POS = -3.0e38, 3.0e38
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class SpectralFrontend:
+    """dmx_audio handle: STFT(n_fft, hop) + mel filterbank, forward and hand-written backward.
+    Equivalent of torchaudio MelSpectrogram(+AmplitudeToDB) / MelScale / torch.stft in the reference."""
+
+    def __init__(self, sample_rate=16000, n_fft=1024, hop_length=160, n_mels=64, window="hann"):
+        self.n_fft, self.hop, self.n_mels, self.bins = n_fft, hop_length, n_mels, n_fft // 2 + 1
+        fb = np.ascontiguousarray(dsp.melscale_fbanks(self.bins, 0.0, float(sample_rate // 2), n_mels, sample_rate))
+        self._h = C.c_void_p(L.lib().dmx_audio_create(n_fft, hop_length, n_mels, 1 if window == "hann" else 0,
+                                                       fb.ctypes.data_as(C.c_void_p)))
+        if not self._h:
+            L.check(-1, "dmx_audio_create")
+        self._state = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().dmx_audio_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def frames(self, length):
+        return 1 + length // self.hop
+
+    def _get_state(self, B, length, device):
+        n = L.lib().dmx_audio_state_bytes(self._h, B, length)
+        if self._state is None or self._state.numel() < n or self._state.device != device:
+            self._state = torch.empty(n, dtype=torch.uint8, device=device)
+        return self._state
+
+    def transform_fwd(self, wav, length, power2=True, to_db=True, lo=_NEG, hi=_POS, out=None):
+        """wav: fp32 cuda (B, >=length) with arbitrary row stride -> (B, frames, n_mels) fp32."""
+        assert wav.dtype == torch.float32 and wav.is_cuda and wav.stride(1) == 1
+        B = wav.shape[0]
+        st = self._get_state(B, length, wav.device)
+        mel = out if out is not None else torch.empty(B, self.frames(length), self.n_mels, dtype=torch.float32, device=wav.device)
+        L.check(L.lib().dmx_audio_transform_fwd(self._h, _p(wav), wav.stride(0), _p(mel), _p(st), B, length, int(power2), int(to_db),
+                                                lo, hi, _stream()), "audio_transform_fwd")
+        self._last = (B, length, power2, to_db, lo, hi)
+        return mel
+
+    def transform_bwd(self, dmel, dwav=None):
+        B, length, power2, to_db, lo, hi = self._last
+        if dwav is None:
+            dwav = torch.empty(B, length, dtype=torch.float32, device=dmel.device)
+        L.check(L.lib().dmx_audio_transform_bwd(self._h, _p(dmel), _p(dwav), dwav.stride(0), _p(self._state), B, length, int(power2),
+                                                int(to_db), lo, hi, 0, _stream()), "audio_transform_bwd")
+        return dwav
+
+    def stft_mag(self, wav, length):
+        B = wav.shape[0]
+        st = self._get_state(B, length, wav.device)
+        mag = torch.empty(B, self.bins, self.frames(length), dtype=torch.float32, device=wav.device)
+        L.check(L.lib().dmx_audio_stft_mag(self._h, _p(wav), wav.stride(0), _p(mag), _p(st), B, length, _stream()), "stft_mag")
+        return mag
+
+    def melscale(self, mag, lo=_NEG, hi=_POS):
+        B, _, T = mag.shape
+        mel = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=mag.device)
+        L.check(L.lib().dmx_audio_melscale(self._h, _p(mag.contiguous()), _p(mel), B, T, lo, hi, _stream()), "melscale")
+        return mel
+
+
+def l2_loss(ref, pred, want_grad=True, gscale=1.0):
+    """per-clip ||ref - pred||_2 over all trailing dims; ref may have batch 1 (broadcast)."""
+    B = pred.shape[0]
+    n = pred[0].numel()
+    ref = ref.contiguous()
+    assert ref[0].numel() == n, (ref.shape, pred.shape)
+    loss = torch.empty(B, dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if want_grad else None
+    L.check(L.lib().dmx_l2_loss(_p(ref), 0 if ref.shape[0] == 1 and B > 1 else n, _p(pred), _p(loss), _p(dpred), B, n, gscale,
+                                _stream()), "l2_loss")
+    return loss, dpred
+
+
+def _as_f32_cuda(x):
+    if not x.is_cuda:
+        raise RuntimeError("diffmusic_amd operators run on the GPU only (HIP library); move the tensor to cuda")
+    return x.to(torch.float32)
+
+
+class BaseOperator:
+    """forward(data) = A(data); transform(x) = supervised-space map; inverse_transform(mel, vocoder)."""
+
+    def transform(self, data, *args, **kwargs):
+        raise NotImplementedError
+
+    def inverse_transform(self, mel_spectrogram, vocoder):      # operator.py:38-42 (six identical copies)
+        if mel_spectrogram.dim() == 4:
+            mel_spectrogram = mel_spectrogram.squeeze(1)
+        return vocoder(mel_spectrogram)
+
+    def forward(self, data, **kwargs):
+        raise NotImplementedError
+
+    # ---- guided-step extension -------------------------------------------------------------
+    _ref_cache = None
+
+    def _ref(self, measurement, fn):
+        key = (measurement.data_ptr(), tuple(measurement.shape), measurement._version)
+        if self._ref_cache is None or self._ref_cache[0] != key:
+            self._ref_cache = (key, fn(measurement))      # `transform(y)` is constant over the trajectory
+        return self._ref_cache[1]
+
+    def guidance(self, wav, length, measurement, supervised_space):
+        raise NotImplementedError
+
+
+class _MelOperator(BaseOperator):
+    """Shared mel plumbing: transform = wav2mel (dB) with optional clamp; returns (B, n_mels, T)."""
+    clamp = (-80.0, 80.0)
+
+    def _init_mel(self, sample_rate=16000):
+        self.frontend = SpectralFrontend(sample_rate, 1024, 160, 64, "hann")
+
+    def _mel(self, audio, length=None):
+        lo, hi = self.clamp if self.clamp else (_NEG, _POS)
+        audio = _as_f32_cuda(audio)
+        return self.frontend.transform_fwd(audio, length or audio.shape[-1], True, True, lo, hi)
+
+    def transform(self, audio):
+        return self._mel(audio).transpose(1, 2)             # torchaudio layout (B, n_mels, frames)
+
+    # A(.) on the vocoder output: subclasses override _a_fwd/_a_bwd
+    def _a_fwd(self, wav, length):
+        raise NotImplementedError
+
+    def _a_bwd(self, dy, wav_full_len):
+        raise NotImplementedError
+
+    def guidance(self, wav, length, measurement, supervised_space):
+        y = self._a_fwd(wav, length)                                         # (B, L') contiguous fp32
+        measurement = _as_f32_cuda(measurement)
+        if supervised_space == "wav_form":
+            loss, dy = l2_loss(measurement.reshape(measurement.shape[0], -1), y)
+        elif supervised_space == "mel_spectrogram":
+            ref = self._ref(measurement, lambda m: self._mel(m.reshape(m.shape[0], -1)).clone())
+            pred = self._mel(y)
+            loss, dmel = l2_loss(ref, pred)
+            dy = self.frontend.transform_bwd(dmel)
+        else:
+            raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
+        return loss, self._a_bwd(dy, wav.shape[1])
+
+
+class IdentityOperator(_MelOperator):                     # operator.py:17-45
+    def __init__(self, sample_rate):
+        self._init_mel(sample_rate)
+
+    def forward(self, data, **kwargs):
+        return data
+
+    def _a_fwd(self, wav, length):
+        y = torch.empty(wav.shape[0], length, dtype=torch.float32, device=wav.device)
+        L.check(L.lib().dmx_mask_apply(_p(wav), wav.stride(0), None, _p(y), length, wav.shape[0], length, length, _stream()), "copy")
+        return y
+
+    def _a_bwd(self, dy, full):
+        B, n = dy.shape
+        d = torch.empty(B, full, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().dmx_mask_apply(_p(dy), n, None, _p(d), full, B, n, full, _stream()), "copy")
+        return d
+
+
+class MusicInpaintingOperator(_MelOperator):              # operator.py:48-133
+    clamp = None                                            # transform = wav2mel without clamp (operator.py:123-124)
+
+    def __init__(self, audio_length_in_s, sample_rate, mask_type, start_inpainting_s, end_inpainting_s, mask_percentage,
+                 mask_duration_s, interval_s, noiser=None):
+        self.audio_length_in_s, self.sample_rate, self.mask_type = audio_length_in_s, sample_rate, mask_type
+        self.start_inpainting_s, self.end_inpainting_s = start_inpainting_s, end_inpainting_s
+        self.mask_percentage, self.interval_s, self.mask_duration_s = mask_percentage, interval_s, mask_duration_s
+        self.mask = self.generate_mask()
+        self._init_mel(sample_rate)
+        self.noiser = noiser
+        self._mask_dev = None
+
+    def generate_mask(self):                                # operator.py:87-121 (host, once)
+        n = int(self.audio_length_in_s * self.sample_rate)
+        mask = torch.ones([1, n])
+        sr = self.sample_rate
+        if self.mask_type == "box":
+            if self.start_inpainting_s is not None and self.end_inpainting_s is not None:
+                mask[:, int(self.start_inpainting_s * sr): int(self.end_inpainting_s * sr)] = 0.
+        elif self.mask_type == "random":
+            dur = int(self.mask_duration_s * sr)
+            count = max(1, int(self.mask_percentage * n) // dur)
+            for _ in range(count):
+                start = int(torch.randint(0, mask.shape[1] - dur, (1,)))
+                mask[:, start:start + dur] = 0.
+        elif self.mask_type == "periodic":
+            interval, dur = int(self.interval_s * sr), int(self.mask_duration_s * sr)
+            for start in range(0, mask.shape[1], interval):
+                mask[:, start:min(start + dur, mask.shape[1])] = 0.
+        return mask
+
+    def _mask_on(self, device):
+        if self._mask_dev is None or self._mask_dev.device != device:
+            self._mask_dev = self.mask.to(device=device, dtype=torch.float32).contiguous()
+        return self._mask_dev
+
+    def forward(self, data, **kwargs):
+        data = _as_f32_cuda(data)
+        B, n = data.shape
+        y = torch.empty(B, n, dtype=torch.float32, device=data.device)
+        L.check(L.lib().dmx_mask_apply(_p(data), data.stride(0), _p(self._mask_on(data.device)), _p(y), n, B, n, n, _stream()), "mask")
+        return self.noiser(y) if self.noiser is not None else y
+
+    def _a_fwd(self, wav, length):
+        if length != self.mask.shape[1]:
+            raise ValueError(f"mask length {self.mask.shape[1]} != waveform length {length}")
+        y = torch.empty(wav.shape[0], length, dtype=torch.float32, device=wav.device)
+        L.check(L.lib().dmx_mask_apply(_p(wav), wav.stride(0), _p(self._mask_on(wav.device)), _p(y), length, wav.shape[0], length,
+                                       length, _stream()), "mask")
+        return y
+
+    def _a_bwd(self, dy, full):
+        B, n = dy.shape
+        d = torch.empty(B, full, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().dmx_mask_apply(_p(dy), n, _p(self._mask_on(dy.device)), _p(d), full, B, n, full, _stream()), "mask_bwd")
+        return d
+
+
+class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
+    def __init__(self, n_fft=1024, hop_length=160, win_length=1024, noiser=None):
+        assert win_length == n_fft
+        self.n_fft, self.hop_length, self.win_length = n_fft, hop_length, win_length
+        self.frontend = SpectralFrontend(16000, n_fft, hop_length, 64, "rect")   # torch.stft(window=None)
+        self.noiser = noiser
+
+    def transform(self, magnitude):                        # clamp(MelScale(mag), -80, 80) -> (B, n_mels, T)
+        return self.frontend.melscale(_as_f32_cuda(magnitude), -80.0, 80.0).transpose(1, 2)
+
+    def forward(self, data, **kwargs):
+        data = _as_f32_cuda(data)
+        mag = self.frontend.stft_mag(data, data.shape[-1])
+        return self.noiser(mag) if self.noiser is not None else mag
+
+    def guidance(self, wav, length, measurement, supervised_space):
+        if supervised_space != "mel_spectrogram":
+            raise NotImplementedError("phase retrieval guidance is implemented in the mel_spectrogram space")
+        measurement = _as_f32_cuda(measurement)
+        ref = self._ref(measurement, lambda m: self.frontend.melscale(m, -80.0, 80.0))
+        pred = self.frontend.transform_fwd(wav, length, False, False, -80.0, 80.0)   # |STFT| -> MelScale -> clamp
+        loss, dmel = l2_loss(ref, pred)
+        dwav = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)
+        self.frontend.transform_bwd(dmel, dwav)
+        return loss, dwav
+
+
+class SuperResolutionOperator(_MelOperator):              # operator.py:174-205
+    def __init__(self, sample_rate, scale=10, noiser=None):
+        self.orig, self.new = sample_rate, sample_rate // scale
+        self._init_mel(16000)
+        self.noiser = noiser
+        raise NotImplementedError("SuperResolutionOperator: polyphase resampler kernel lands in the next milestone")
+
+
+class MusicDereverberationOperator(_MelOperator):         # operator.py:208-250
+    def __init__(self, ir_length=800, decay_factor=0.85, noiser=None):
+        self.ir_length, self.decay_factor = ir_length, decay_factor
+        self._init_mel(16000)
+        self.noiser = noiser
+        raise NotImplementedError("MusicDereverberationOperator: FIR kernel lands in the next milestone")

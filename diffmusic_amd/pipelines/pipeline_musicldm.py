@@ -1,0 +1,204 @@
+"""MusicLDM pipeline facade with the reference's `__call__` surface
+(diffmusic/pipelines/pipeline_musicldm.py:491-799): geometry, prepare_latents, the denoising loop
+(U-Net on the CFG batch -> CFG combine -> scheduler.step), NaN-retry, final decode.
+
+In scope: everything inside and right around the loop.
+Out of scope: the CLAP text encoder -- pass `prompt_embeds` (and optionally
+`negative_prompt_embeds`) directly, exactly as the reference signature allows.
+Extension: all B clips are returned (the reference returns clip 0 only, :781)."""
+import contextlib
+import inspect
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..engine import HifiGanEngine, UNetEngine, VaeDecoderEngine
+from ..torch_utils import randn_tensor
+
+import ctypes as C
+
+
+class AudioPipelineOutput(SimpleNamespace):
+    pass
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MusicLDMPipeline:
+    def __init__(self, vae, unet, vocoder, scheduler=None):
+        self.vae, self.unet, self.vocoder, self.scheduler = vae, unet, vocoder, scheduler
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        self.device = torch.device("cuda")
+        self.nan_check_every = 1          # host check of the loss every k steps (reference: every step, :742)
+        self.dedupe_cfg = False           # opt-in: run one U-Net pass when cond == uncond
+
+    # ---- construction ---------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, repo_id, torch_dtype=None, seed=0, unet_config=None, vae_config=None, vocoder_config=None, **kw):
+        """`repo_id` may be a local directory with {unet,vae,vocoder}/*.safetensors in the upstream naming, or
+        "synthetic" (seeded variance-preserving weights of the benchmark architecture; no checkpoint exists offline)."""
+        unet, vae, voc = UNetEngine(unet_config), VaeDecoderEngine(vae_config), HifiGanEngine(vocoder_config)
+        if os.path.isdir(str(repo_id)):
+            from safetensors.torch import load_file
+            for eng, sub in ((unet, "unet"), (vae, "vae"), (voc, "vocoder")):
+                files = [f for f in os.listdir(os.path.join(repo_id, sub)) if f.endswith(".safetensors")]
+                sd = {}
+                for f in files:
+                    sd.update(load_file(os.path.join(repo_id, sub, f)))
+                eng.load_state_dict(sd)
+        else:
+            for i, eng in enumerate((unet, vae, voc)):
+                eng.load_state_dict(eng.synth_state_dict(seed=seed + i))
+        return cls(vae, unet, voc)
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    # ---- helpers --------------------------------------------------------------------------
+    def prepare_extra_step_kwargs(self, generator, eta):          # pipeline_musicldm.py:335-343
+        params = set(inspect.signature(self.scheduler.step).parameters.keys())
+        extra = {}
+        if "eta" in params:
+            extra["eta"] = eta
+        if "generator" in params:
+            extra["generator"] = generator
+        return extra
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, dtype, device, generator, latents=None):   # :406-426
+        shape = (batch_size, num_channels_latents, int(height) // self.vae_scale_factor,
+                 int(self.vocoder.config.model_in_dim) // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    def mel_spectrogram_to_waveform(self, mel_spectrogram):       # :428-435
+        if mel_spectrogram.dim() == 4:
+            mel_spectrogram = mel_spectrogram.squeeze(1)
+        return self.vocoder(mel_spectrogram).cpu().float()
+
+    def save_mel_spectrogram(self, mel_spectrogram, path, sample_rate=16000, hop_length=160, gt_mel_spectrogram=None,
+                             gt_sample_rate=16000, title="Mel-Spectrogram"):     # :462-489
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        m = torch.as_tensor(mel_spectrogram).detach().float().cpu().squeeze().numpy()
+        n = 2 if gt_mel_spectrogram is not None else 1
+        fig, axes = plt.subplots(n, 1, figsize=(10, 4 * n), squeeze=False)
+        axes[0][0].imshow(m, origin="lower", aspect="auto")
+        axes[0][0].set_title(title)
+        if gt_mel_spectrogram is not None:
+            axes[1][0].imshow(torch.as_tensor(gt_mel_spectrogram).float().cpu().squeeze().numpy(), origin="lower", aspect="auto")
+            axes[1][0].set_title("ground truth")
+        fig.savefig(path)
+        plt.close(fig)
+
+    def _unet_eps(self, latents, t_host, prompt_embeds2, guidance_scale, do_cfg):
+        """U-Net on the (2B) CFG batch + combine (pipeline_musicldm.py:692-708), all HIP."""
+        x = latents.to(torch.float32).contiguous()
+        B = x.shape[0]
+        if not do_cfg:
+            return self.unet.forward(x, torch.full((B,), float(t_host)), prompt_embeds2)
+        if self.dedupe_cfg and torch.equal(prompt_embeds2[:B], prompt_embeds2[B:]):
+            return self.unet.forward(x, torch.full((B,), float(t_host)), prompt_embeds2[:B])     # uncond + s*(text-uncond) == text
+        x2 = torch.cat([x, x], dim=0)
+        eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host)), prompt_embeds2)
+        out = torch.empty_like(x)
+        L.check(L.lib().dmx_sched_cfg_combine(C.c_void_p(eps2.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(), float(guidance_scale),
+                                              _stream()), "cfg_combine")
+        return out
+
+    # ---- the call ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, prompt=None, audio_length_in_s=None, num_inference_steps=200, guidance_scale=2.0, negative_prompt=None,
+                 num_waveforms_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, return_dict=True, callback=None, callback_steps=1, cross_attention_kwargs=None,
+                 output_type="np", measurement=None, optim_prompt=False, ip_guidance_rate=0.0005,
+                 optim_prompt_learning_rate=0.0001, optim_outer_loop=1, show_progress=True, prompt_type=None,
+                 supervised_space="mel_spectrogram"):
+        if prompt_embeds is None:
+            raise NotImplementedError("the CLAP text encoder is out of scope of this engine: pass prompt_embeds (B, 512)")
+        if optim_prompt:
+            raise NotImplementedError("optim_prompt is a no-op in the reference and disabled in every config")
+        vcfg = self.vocoder.config
+        vocoder_upsample_factor = np.prod(vcfg.upsample_rates) / vcfg.sampling_rate               # :602
+        if audio_length_in_s is None:
+            audio_length_in_s = 10.24
+        height = int(audio_length_in_s / vocoder_upsample_factor)
+        original_waveform_length = int(audio_length_in_s * vcfg.sampling_rate)
+        if height % self.vae_scale_factor != 0:
+            height = int(np.ceil(height / self.vae_scale_factor)) * self.vae_scale_factor
+        device = self.device
+        batch_size = prompt_embeds.shape[0]
+        do_cfg = guidance_scale > 1.0
+        pe = prompt_embeds.to(device=device, dtype=torch.float32)
+        pe = pe.repeat_interleave(num_waveforms_per_prompt, dim=0)
+        if do_cfg:
+            ne = negative_prompt_embeds if negative_prompt_embeds is not None else prompt_embeds     # prompt="" -> cond == uncond
+            ne = ne.to(device=device, dtype=torch.float32).repeat_interleave(num_waveforms_per_prompt, dim=0)
+            pe = torch.cat([ne, pe], dim=0)                                                          # [uncond | text]  (:243-248)
+        self.scheduler.set_timesteps(num_inference_steps, device=device)
+        timesteps = list(self.scheduler._timesteps_host)
+        nlat = self.unet.cfg["in_channels"]
+        B = batch_size * num_waveforms_per_prompt
+        latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, latents)
+        extra = self.prepare_extra_step_kwargs(generator, eta)
+        if measurement is not None:
+            measurement = measurement.to(device)
+        init_latents = latents
+        self.last_losses = []
+        for _ in range(optim_outer_loop):
+            retry = 10
+            latents = init_latents
+            while True:
+                is_done = True
+                pending = []
+                bar = None
+                if show_progress:
+                    from tqdm import tqdm
+                    bar = tqdm(total=num_inference_steps)
+                with bar if bar is not None else contextlib.nullcontext():
+                    for i, t in enumerate(timesteps):
+                        noise_pred = self._unet_eps(self.scheduler.scale_model_input(latents, t), t, pe, guidance_scale, do_cfg)
+                        out = self.scheduler.step(noise_pred, t, latents, measurement=measurement,
+                                                  original_waveform_length=original_waveform_length, vae=self.vae,
+                                                  vocoder=self.vocoder, ip_guidance_rate=ip_guidance_rate,
+                                                  ditto_optimizer=None, init_latents=init_latents,
+                                                  supervised_space=supervised_space, **extra)
+                        pending.append(out.loss)
+                        last = i == len(timesteps) - 1
+                        if (len(pending) >= self.nan_check_every or last) and retry >= 0:
+                            bad = any(bool(torch.isnan(l.float()).any()) for l in pending)      # one host sync per check
+                            self.last_losses.extend(pending)
+                            pending = []
+                            if bad:                                                             # NaN-retry (:741-756)
+                                retry -= 1
+                                latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, None)
+                                is_done = False
+                                break
+                        latents = out.prev_sample.detach()
+                        if bar is not None:
+                            bar.update()
+                        if callback is not None and i % callback_steps == 0:
+                            callback(i, t, latents)
+                if is_done:
+                    break
+        if output_type == "latent":
+            return AudioPipelineOutput(audios=latents)
+        mel = self.vae.decode(latents / self.vae.config.scaling_factor).sample                 # (B,1,H,W) fp32
+        audio = self.mel_spectrogram_to_waveform(mel)[:, :original_waveform_length]
+        if output_type == "np":
+            audio = audio.numpy()
+        if not return_dict:
+            return (audio,)
+        return AudioPipelineOutput(audios=audio)

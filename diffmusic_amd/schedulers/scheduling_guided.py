@@ -1,0 +1,192 @@
+"""The five in-scope schedulers behind the reference's Scheduler protocol:
+same constructor keys (configs/model/*.yaml `scheduler:`), `set_timesteps`, `timesteps`,
+`scale_model_input`, `init_noise_sigma`, `order`, `config`, and `step(...)` with the reference's
+signature (diffmusic/schedulers/scheduling_dps.py:137-156 and siblings).
+
+Host side = DDIM tables and per-step scalars (fp32, computed once; no device sync per step).
+Device side = HIP: x0 prediction, VAE decode, HiFi-GAN, measurement operator, mel, L2 loss, the
+hand-written backward sweep and the fused update kernel (csrc/sched.hip).  There is no autograd and
+no CPU fallback."""
+import ctypes as C
+from types import SimpleNamespace
+import numpy as np
+import torch
+
+from .. import _lib as L
+from ..torch_utils import randn_tensor
+from .utils import InverseProblemSchedulerOutput
+
+_MODE = dict(ddim=0, dps=1, mpgd=2, dsg=3, diffmusic=4)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class GuidedDDIMScheduler:
+    """Common base: diffusers-0.31.0-compatible DDIM tables + the HIP guided step."""
+    order = 1
+    init_noise_sigma = 1.0
+    mode = "ddim"
+    default_eta = 0.0
+    default_rate = 0.0
+    passes_eta_to_parent = False      # DPS/MPGD: parent DDIM step consumes one randn draw when eta > 0
+
+    def __init__(self, operator=None, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
+                 thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
+                 timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, *args, **kwargs):
+        if prediction_type != "epsilon" or clip_sample or thresholding or rescale_betas_zero_snr:
+            raise NotImplementedError("only epsilon prediction without clipping/thresholding (the reference's configs) is built")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, trained_betas=trained_betas, clip_sample=clip_sample,
+                                      set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset,
+                                      prediction_type=prediction_type, thresholding=thresholding,
+                                      timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr)
+        if trained_betas is not None:
+            betas = torch.tensor(trained_betas, dtype=torch.float32)
+        elif beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(f"{beta_schedule} is not implemented")
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)            # fp32, host
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self._ac = self.alphas_cumprod.numpy()
+        self.operator = operator
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self.grad_target = grad_target
+        self.last_grad = None
+        self.debug_keep_grad = False
+
+    # ---- protocol pieces the pipelines touch
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        n_train = self.config.num_train_timesteps
+        if num_inference_steps > n_train:
+            raise ValueError("num_inference_steps > num_train_timesteps")
+        self.num_inference_steps = num_inference_steps
+        sp = self.config.timestep_spacing
+        if sp == "leading":
+            ratio = n_train // num_inference_steps
+            ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        elif sp == "trailing":
+            ts = np.round(np.arange(n_train, 0, -n_train / num_inference_steps)).astype(np.int64) - 1
+        elif sp == "linspace":
+            ts = np.linspace(0, n_train - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+        else:
+            raise ValueError(f"{sp} is not supported")
+        self._timesteps_host = [int(t) for t in ts]
+        self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = float(self._ac[timestep])
+        a_p = float(self._ac[prev_timestep]) if prev_timestep >= 0 else float(self.final_alpha_cumprod)
+        return (1 - a_p) / (1 - a_t) * (1 - a_t / a_p)
+
+    def _scalars(self, timestep, eta):
+        t = int(timestep)                       # a device tensor here costs one sync; the pipeline passes host ints
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = float(self._ac[t])
+        a_p = float(self._ac[prev_t]) if prev_t >= 0 else float(self.final_alpha_cumprod)
+        sigma = eta * self._get_variance(t, prev_t) ** 0.5
+        return t, a_t, a_p, sigma
+
+    # ---- HIP guidance sweep: x0 -> vae -> vocoder -> A -> loss ; and back
+    def _guidance(self, x0, measurement, vae, vocoder, length, supervised_space):
+        zs = 1.0 / vae.config.scaling_factor
+        mel = vae.decode_hip(x0, z_scale=zs, keep_state=True)              # (B, H, W) fp16
+        wav = vocoder.forward(mel)                                         # (B, Lfull) fp32
+        loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space)
+        inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
+        L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
+                "grad_normalize")
+        dmel = vocoder.backward(dwav)
+        g0 = vae.backward(dmel, z_scale=zs)                                # dLoss/dx0 * (1/inv_scale)
+        return loss, g0, inv_scale
+
+    def step(self, model_output, timestep, sample, eta=None, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict=True, measurement=None, ip_guidance_rate=None, vae=None, vocoder=None,
+             original_waveform_length=0, supervised_space="mel_spectrogram", eps=1e-8, *args, **kwargs):
+        eta = self.default_eta if eta is None else eta
+        rate = self.default_rate if ip_guidance_rate is None else ip_guidance_rate
+        if supervised_space not in ("wav_form", "mel_spectrogram"):
+            raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
+        if variance_noise is not None and generator is not None and eta > 0:
+            raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                             " `variance_noise` stays `None`.")
+        if not sample.is_cuda:
+            raise RuntimeError("diffmusic_amd schedulers run on the GPU only (no CPU fallback)")
+        t, a_t, a_p, sigma = self._scalars(timestep, eta)
+        x = sample.detach().to(torch.float32).contiguous()
+        e = model_output.detach().to(torch.float32).contiguous()
+        B, n = x.shape[0], x[0].numel()
+        lib = L.lib()
+        x0 = torch.empty_like(x)
+        L.check(lib.dmx_sched_pred_x0(_p(x), _p(e), _p(x0), x.numel(), a_t, _stream()), "pred_x0")
+        mode = _MODE[self.mode]
+        noise = None
+        if self.mode in ("dps", "mpgd") and eta > 0:
+            if variance_noise is None:
+                if self.passes_eta_to_parent:          # keep the reference's RNG stream
+                    randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+                variance_noise = randn_tensor(model_output.shape, generator=generator, device=model_output.device,
+                                              dtype=model_output.dtype)
+            noise = variance_noise.to(torch.float32).contiguous()
+        loss = g0 = inv_scale = None
+        if self.mode == "ddim":
+            loss = torch.tensor([t])
+        else:
+            loss, g0, inv_scale = self._guidance(x0, measurement, vae, vocoder, original_waveform_length, supervised_space)
+            if self.mode in ("dsg", "diffmusic"):
+                sn = kwargs.get("sample_noise")
+                if sn is None:
+                    sn = randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
+                noise = sn.to(torch.float32).contiguous()
+        prev = torch.empty_like(x)
+        x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
+        grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
+        L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out), _p(grad_out),
+                                   B, n, a_t, a_p, sigma, float(rate), float(eps), 0, _stream()), "sched_step")
+        self.last_grad = grad_out
+        if loss.numel() == 1 and self.mode != "ddim":
+            loss = loss.reshape(())
+        return InverseProblemSchedulerOutput(prev_sample=prev.to(sample.dtype),
+                                             pred_original_sample=(x0_out if x0_out is not None else x0).to(sample.dtype),
+                                             loss=loss)
+
+    def optim_prompt(self, model_output, timestep, sample, encoder_hidden_states=None, encoder_hidden_states_1=None, **kwargs):
+        """Signature only: a no-op in the reference (scheduling_dps.py:63-135 discards its requires_grad clones) and
+        disabled in every shipped config (`optim_prompt: false`)."""
+        return InverseProblemSchedulerOutput(encoder_hidden_states=encoder_hidden_states,
+                                             encoder_hidden_states_1=encoder_hidden_states_1)
+
+
+class DDIMScheduler(GuidedDDIMScheduler):        # scheduling_ddim.py:58-104 (the formula; the reference body crashes)
+    mode = "ddim"
+
+
+class DPSScheduler(GuidedDDIMScheduler):         # scheduling_dps.py:137-219
+    mode, default_eta, default_rate, passes_eta_to_parent = "dps", 0.0, 5e-4, True
+
+
+class MPGDScheduler(GuidedDDIMScheduler):        # scheduling_mpgd.py:137-224
+    mode, default_eta, default_rate, passes_eta_to_parent = "mpgd", 0.0, 1.0, True
+
+
+class DSGScheduler(GuidedDDIMScheduler):         # scheduling_dsg.py:148-230
+    mode, default_eta, default_rate = "dsg", 1.0, 0.08
+
+
+class DiffMusicScheduler(GuidedDDIMScheduler):   # scheduling_diffmusic.py:148-229
+    mode, default_eta, default_rate = "diffmusic", 0.0, 0.08

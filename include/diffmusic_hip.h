@@ -113,6 +113,50 @@ size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w);
 int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h,
                  int w, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- STFT / mel measurement path (fp32): replaces torchaudio MelSpectrogram + AmplitudeToDB / MelScale and
+ * torch.stft as used by the operators (diffmusic/inverse_problem/operator.py:23-33,143-147,162-170) and the
+ * autograd sweep through them (diffmusic/schedulers/scheduling_dps.py:202-212) ------------------------------- */
+typedef struct dmx_audio dmx_audio;
+/* fb_host: (n_fft/2+1, n_mels) fp32 mel filterbank in host memory; window_hann: 1 = periodic hann, 0 = rectangular */
+dmx_audio* dmx_audio_create(int n_fft, int hop, int n_mels, int window_hann, const float* fb_host);
+void dmx_audio_destroy(dmx_audio* a);
+int dmx_audio_num_frames(const dmx_audio* a, int L);
+size_t dmx_audio_state_bytes(const dmx_audio* a, int batch, int L);
+/* wav (B, L) fp32 (row stride wav_stride) -> mel_out (B, frames, n_mels) fp32.  power2: |X|^2 (1) or |X| (0);
+ * to_db: 10*log10(max(.,1e-10)); then clamp(lo, hi).  `state` keeps the spectrum for the backward call. */
+int dmx_audio_transform_fwd(dmx_audio* a, const float* wav, long long wav_stride, float* mel_out, void* state, int batch, int L,
+                            int power2, int to_db, float lo, float hi, void* stream);
+/* dmel (B, frames, n_mels) -> dwav (B, L) (row stride dwav_stride), same flags as the forward call */
+int dmx_audio_transform_bwd(dmx_audio* a, const float* dmel, float* dwav, long long dwav_stride, void* state, int batch, int L,
+                            int power2, int to_db, float lo, float hi, int accumulate, void* stream);
+/* PhaseRetrievalOperator.forward: |torch.stft(wav)| as (B, n_fft/2+1, frames) fp32 */
+int dmx_audio_stft_mag(dmx_audio* a, const float* wav, long long wav_stride, float* mag, void* state, int batch, int L, void* stream);
+/* PhaseRetrievalOperator.transform on a given magnitude (B, bins, frames) -> (B, frames, n_mels) */
+int dmx_audio_melscale(dmx_audio* a, const float* mag, float* mel_out, int batch, int frames, float lo, float hi, void* stream);
+/* MusicInpaintingOperator.forward (operator.py:132-133): y[b,t] = x[b,t]*mask[t] (t<L), 0 for L<=t<Ly; mask NULL = copy */
+int dmx_mask_apply(const float* x, long long x_stride, const float* mask, float* y, long long y_stride, int batch, int L, int Ly,
+                   void* stream);
+/* per-clip loss[b] = ||ref_b - pred_b||_2 (torch.linalg.norm, scheduling_dps.py:211) and dpred = gscale * dloss/dpred */
+int dmx_l2_loss(const float* ref, long long ref_stride, const float* pred, float* loss, float* dpred, int batch, long long n,
+                float gscale, void* stream);
+/* per-clip x *= target/max|x| ; inv_scale[b] = max|x|/target  (keeps the fp16 backward sweep in range) */
+int dmx_grad_normalize(float* x, float* inv_scale, int batch, long long n, float target, void* stream);
+
+/* ---- scheduler arithmetic (diffmusic/schedulers/scheduling_{ddim,dps,mpgd,dsg,diffmusic}.py step bodies) -------------- */
+#define DMX_SCHED_DDIM 0
+#define DMX_SCHED_DPS 1
+#define DMX_SCHED_MPGD 2
+#define DMX_SCHED_DSG 3
+#define DMX_SCHED_DIFFMUSIC 4
+/* x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t) */
+int dmx_sched_pred_x0(const float* x, const float* eps, float* x0, long long n, float alpha_t, void* stream);
+/* classifier-free guidance combine on a (2B, ...) U-Net output (pipeline_musicldm.py:706-708) */
+int dmx_sched_cfg_combine(const float* eps2, float* out, long long n, float scale, void* stream);
+/* fused update: g0 = dLoss/dx0 (times 1/inv_scale[b]); see csrc/sched.hip for the per-mode formulas */
+int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
+                   const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
+                   float sigma, float rate, float eps_small, int global_norm, void* stream);
+
 /* ---- low-level test hook: one implicit-GEMM launch described by the internal descriptor --------*/
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
 

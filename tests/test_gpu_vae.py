@@ -25,7 +25,7 @@ def test_vae_decode_fwd_bwd_vs_oracle(B, h, w):
     z = torch.randn(B, 8, h, w, generator=g)
     dmel = torch.randn(B, 4 * h, 4 * w, generator=g)
     zs = 1.0 / SMALL["scaling_factor"]
-    mel, mel32 = eng.decode(z.cuda(), z_scale=zs, want_f32=True)
+    mel, mel32 = eng.decode_hip(z.cuda(), z_scale=zs, want_f32=True)
     dz = eng.backward(dmel.to(L.act_dtype()).cuda(), z_scale=zs)
     torch.cuda.synchronize()
     zr = z.clone().requires_grad_(True)
