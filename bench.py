@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoising steps/sec, MusicLDM + DPS music_inpainting, 10 s @16 kHz clips,
+200-step schedule, batch 8 per GPU (BASELINE.json configs[1]).  One "step" = one pass of the hot loop
+over the batch: U-Net on the 2B CFG batch -> CFG combine -> DPSScheduler.step (x0, VAE decode,
+HiFi-GAN, mask, log-mel, L2, hand-written backward sweep, fused update).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  Weights are seeded synthetic (no checkpoints offline), clips are
+synthetic sums of sinusoids; inputs are resident in HBM before the timed region.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SCHED_CFG = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear",
+                 trained_betas=None, clip_sample=False, set_alpha_to_one=False, steps_offset=1, prediction_type="epsilon",
+                 thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
+                 timestep_spacing="leading", rescale_betas_zero_snr=False)
+SR, SECONDS, N_STEPS, ZETA, GUIDANCE_SCALE = 16000, 10, 200, 5e-4, 2.0
+ALGO_TFLOP_PER_CLIP_STEP = 3.52        # BASELINE.md section 2 (U-Net 2x fwd + VAE fwd/dgrad + HiFi-GAN fwd/dgrad)
+PEAK_TFLOPS_16BIT = 2500.0             # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synth_clip(k, length):
+    """y_k(n) = 0.5*sum_j a_j sin(2 pi f_j n / sr + phi_j) + 0.01 N(0,1), seeded per clip."""
+    g = torch.Generator().manual_seed(1000 + k)
+    f = torch.exp(torch.empty(4).uniform_(math.log(55.0), math.log(7000.0), generator=g))
+    a = torch.empty(4).uniform_(0.2, 1.0, generator=g)
+    ph = torch.empty(4).uniform_(0, 2 * math.pi, generator=g)
+    n = torch.arange(length, dtype=torch.float32)
+    y = 0.5 * (a[:, None] * torch.sin(2 * math.pi * f[:, None] * n[None] / SR + ph[:, None])).sum(0)
+    return (y + 0.01 * torch.randn(length, generator=g)).clamp(-1, 1)
+
+
+def build_problem(B, rank, device):
+    from diffmusic_amd.pipelines import get_pipeline
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd.inverse_problem import MusicInpaintingOperator, get_noiser
+    from diffmusic_amd.torch_utils import randn_tensor
+    pipe = get_pipeline("musicldm").from_pretrained("synthetic", seed=0).to(device)
+    op = MusicInpaintingOperator(SECONDS, SR, "box", 2, 3, 0.3, 0.1, 1.0, noiser=get_noiser("gaussian", 0.0))
+    pipe.scheduler = get_scheduler("dps")(operator=op, **SCHED_CFG)
+    pipe.scheduler.set_timesteps(N_STEPS, device=device)
+    L = SECONDS * SR
+    clips = torch.stack([synth_clip(rank * B + i, L) for i in range(B)]).to(device)
+    measurement = op.forward(clips)
+    gens = [torch.Generator().manual_seed(rank * B + i) for i in range(B)]
+    latents = randn_tensor((B, 8, 250, 16), generator=gens, device=device, dtype=torch.float32)
+    pe = torch.nn.functional.normalize(torch.randn(B, 512, generator=torch.Generator().manual_seed(7)), dim=-1).to(device)
+    pe2 = torch.cat([pe, pe], dim=0)          # prompt="" in the reference: cond == uncond, CFG batch kept at 2B
+    return pipe, op, measurement, latents, pe2, L
+
+
+def one_step(pipe, latents, t, pe2, measurement, L):
+    eps = pipe._unet_eps(latents, t, pe2, GUIDANCE_SCALE, True)
+    out = pipe.scheduler.step(eps, t, latents, eta=0.0, measurement=measurement, vae=pipe.vae, vocoder=pipe.vocoder,
+                              original_waveform_length=L, ip_guidance_rate=ZETA, supervised_space="mel_spectrogram")
+    return out.prev_sample, out.loss
+
+
+def cpu_baseline(seed_sd, threads):
+    """The CPU restatement (oracle/, fp32 eager torch + autograd) timed on the host cores: 1 clip x 1 DPS step."""
+    from oracle import models as OM, operators as OO, schedulers as OS
+    torch.set_num_threads(threads)
+    unet, vae, voc = OM.UNetMusicLDM().eval(), OM.VaeDecoder().eval(), OM.HifiGan().eval()
+    unet.load_state_dict(seed_sd["unet"], strict=True)
+    vae.load_state_dict(seed_sd["vae"], strict=True)
+    voc.load_state_dict(seed_sd["vocoder"], strict=False)
+    op = OO.MusicInpaintingOperator(SECONDS, SR, "box", 2, 3, 0.3, 0.1, 1.0, noiser=OO.get_noiser("gaussian", 0.0))
+    sched = OS.DPSScheduler(operator=op, **SCHED_CFG)
+    sched.set_timesteps(N_STEPS)
+    L = SECONDS * SR
+    y = op.forward(synth_clip(0, L)[None])
+    x = torch.randn(1, 8, 250, 16, generator=torch.Generator().manual_seed(0))
+    pe = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(7)), dim=-1)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        e2 = unet(torch.cat([x, x]), 996, class_labels=torch.cat([pe, pe]))[0]
+    e = e2[:1] + GUIDANCE_SCALE * (e2[1:] - e2[:1])
+    sched.step(e, 996, x, eta=0.0, measurement=y, vae=vae, vocoder=voc, original_waveform_length=L,
+               ip_guidance_rate=ZETA, supervised_space="mel_spectrogram")
+    return time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    B = args.batch
+    pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device)
+    ts = pipe.scheduler._timesteps_host
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(args.warmup):
+        latents, _ = one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+        k += 1
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    loss = None
+    for _ in range(args.steps):
+        latents, loss = one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+        k += 1
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    finite = bool(torch.isfinite(loss).all()) and bool(torch.isfinite(latents).all())
+
+    # ---- roofline leg: one extra step with HIP events around every implicit-GEMM launch
+    import ctypes as C
+    from diffmusic_amd import _lib as Lb
+    Lb.lib().dmx_prof_begin()
+    one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+    ms, fl = C.c_double(), C.c_double()
+    n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
+    algo_tflop_step = ALGO_TFLOP_PER_CLIP_STEP * B
+    achieved = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": None,
+                "kernel": "gemm_kernel<128,*> (implicit-GEMM conv / batched NT GEMM, fp16 MFMA)",
+                "launches_per_step": n_launch, "kernel_ms_per_step": round(ms.value, 3),
+                "issued_tflop_per_step": round(fl.value / 1e12, 2), "algorithmic_tflop_per_step": algo_tflop_step,
+                "step_share": round(ms.value / (1e3 * wall / args.steps), 3)}
+
+    if rank == 0:
+        steps_per_s = args.steps / wall * world                 # one step advances B clips on each of `world` GPUs
+        res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4),
+               "unit": "steps/s (each step advances a batch of 8 clips)", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU "
+                                      "(BASELINE.json configs[1])", "global_batch": B * world, "clips_per_gpu": B,
+                          "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world}",
+                          "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite,
+                          "final_loss_clip0": float(loss.reshape(-1)[0])},
+               "roofline": roofline}
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share, not the host's core count
+            sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
+            sec = cpu_baseline(sd, threads)
+            res["cpu_baseline"] = {"value": round(1.0 / (sec * B), 6), "unit": "steps/s (batch-8 equivalent, extrapolated from 1 clip)",
+                                   "cores": threads, "kind": "port",
+                                   "sample": f"1 clip x 1 DPS step (U-Net 2x fwd + guided step), fp32 eager torch + autograd, {sec:.1f} s"}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

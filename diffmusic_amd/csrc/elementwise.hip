@@ -91,36 +91,51 @@ __global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __re
   }
 }
 
-// combine partials -> stats[b,g] = (mean, rstd); scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+// combine partials -> stats[b,g] = (mean, rstd); scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma.
+// 8 lanes per group walk the chunk partials in parallel (two passes: weighted mean, then M2 about it).
+__device__ __forceinline__ float sum8(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ stats,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    int P, int C, int G, int nchunk, int ppb, float eps) {
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x, cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
+  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  if (g < G) {
+    float sw = 0.f, sn = 0.f;
+    for (int k = sub; k < nchunk; k += 8) {
       const int cnt = min(P, (k + 1) * ppb) - k * ppb;
-      if (cnt <= 0) break;
+      const float nb = (float)cnt * cpg;
+      sw += nb * partial[(((long long)b * nchunk + k) * G + g) * 2];
+      sn += nb;
+    }
+    sw = sum8(sw); sn = sum8(sn);
+    const float mean = sw / sn;
+    float m2 = 0.f;
+    for (int k = sub; k < nchunk; k += 8) {
+      const int cnt = min(P, (k + 1) * ppb) - k * ppb;
       const float nb = (float)cnt * cpg;
       const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
-      const float delta = pp[0] - mean, nn = n + nb;
-      mean += delta * nb / nn;
-      m2 += pp[1] + delta * delta * n * nb / nn;
-      n = nn;
+      const float d = pp[0] - mean;
+      m2 += pp[1] + nb * d * d;
     }
-    const float rstd = rsqrtf(m2 / n + eps);
-    s_mean[g] = mean; s_rstd[g] = rstd;
-    stats[((long long)b * G + g) * 2] = mean;
-    stats[((long long)b * G + g) * 2 + 1] = rstd;
+    m2 = sum8(m2);
+    if (sub == 0) {
+      const float rstd = rsqrtf(m2 / sn + eps);
+      s_mean[g] = mean; s_rstd[g] = rstd;
+      stats[((long long)b * G + g) * 2] = mean;
+      stats[((long long)b * G + g) * 2 + 1] = rstd;
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float a = s_rstd[g] * gamma[c];
+    const int gg = c / cpg;
+    const float a = s_rstd[gg] * gamma[c];
     scale[(long long)b * C + c] = a;
-    shift[(long long)b * C + c] = beta[c] - s_mean[g] * a;
+    shift[(long long)b * C + c] = beta[c] - s_mean[gg] * a;
   }
 }
 
@@ -149,29 +164,33 @@ __global__ void gn_apply_kernel(const act_t* __restrict__ x, const float* __rest
 }
 
 // backward finalize: per (b,c) coefficients k0, k1 with dx = scale*dy*act'(z) + k0 + k1*x
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+__global__ __launch_bounds__(512) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
                                        float* __restrict__ k0, float* __restrict__ k1,
                                        int P, int C, int G, int nchunk) {
   __shared__ float s_c1[64], s_c2[64];
   const int b = blockIdx.x, cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  if (g < G) {
     float a = 0.f, q = 0.f;
-    for (int k = 0; k < nchunk; ++k) {
+    for (int k = sub; k < nchunk; k += 8) {
       const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
       a += pp[0]; q += pp[1];
     }
-    const float n = (float)P * cpg;
-    s_c1[g] = a / n;   // mean(dz*gamma*rstd)          (rstd already folded in via `scale`)
-    s_c2[g] = q / n;   // mean(dz*gamma*rstd * xhat)
+    a = sum8(a); q = sum8(q);
+    if (sub == 0) {
+      const float n = (float)P * cpg;
+      s_c1[g] = a / n;   // mean(dz*gamma*rstd)          (rstd already folded in via `scale`)
+      s_c2[g] = q / n;   // mean(dz*gamma*rstd * xhat)
+    }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float mean = stats[((long long)b * G + g) * 2], rstd = stats[((long long)b * G + g) * 2 + 1];
+    const int gg = c / cpg;
+    const float mean = stats[((long long)b * G + gg) * 2], rstd = stats[((long long)b * G + gg) * 2 + 1];
     // dx = rstd*(dxhat - mean(dxhat) - xhat*mean(dxhat*xhat)), with rstd*dxhat == scale*dz
     // => dx = scale*dz - c1 - c2*rstd*(x-mean)
-    k0[(long long)b * C + c] = -s_c1[g] + s_c2[g] * rstd * mean;
-    k1[(long long)b * C + c] = -s_c2[g] * rstd;
+    k0[(long long)b * C + c] = -s_c1[gg] + s_c2[gg] * rstd * mean;
+    k1[(long long)b * C + c] = -s_c2[gg] * rstd;
   }
 }
 
@@ -233,23 +252,45 @@ __global__ void layernorm_kernel(const act_t* __restrict__ x, const float* __res
 }
 
 // ------------------------------------------------------------------------------ softmax
-// S fp32 (rows, N) ld=lds -> P bf16 (rows, N) ld=ldp; optional additive column bias (mask)
-__global__ void softmax_kernel(const float* __restrict__ S, act_t* __restrict__ P, const float* __restrict__ colbias,
-                               int N, long long lds, long long ldp, int rows_per_bias) {
+// S fp32 (rows, N) ld=lds -> P fp16 (rows, N) ld=ldp; optional additive column bias (mask).
+// Single pass: TPR threads own one row and keep it in registers (<= 16 values per thread, N <= 16*TPR).
+template <int TPR>
+__global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ S, act_t* __restrict__ P, const float* __restrict__ colbias,
+                                                      long long rows, int N, long long lds, long long ldp, int rows_per_bias) {
   __shared__ float sh[16];
-  const long long row = blockIdx.x;
-  const float* s = S + row * lds;
-  const float* cb = colbias ? colbias + (row / rows_per_bias) * N : nullptr;
+  constexpr int RPB = 256 / TPR;
+  const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TPR;
+  const int t = threadIdx.x % TPR;
+  const bool live = row < rows;
+  const float* s = S + (live ? row : 0) * lds;
+  const float* cb = colbias ? colbias + ((live ? row : 0) / rows_per_bias) * N : nullptr;
+  float v[16];
   float mx = -3.0e38f;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) mx = fmaxf(mx, s[i] + (cb ? cb[i] : 0.f));
-  mx = block_max(mx, sh);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = (q * TPR + t) * 4;
+    float4 x = make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+    if (live && c < N) {
+      x = *reinterpret_cast<const float4*>(s + c);
+      if (cb) { const float4 bb = *reinterpret_cast<const float4*>(cb + c); x.x += bb.x; x.y += bb.y; x.z += bb.z; x.w += bb.w; }
+    }
+    v[q * 4] = x.x; v[q * 4 + 1] = x.y; v[q * 4 + 2] = x.z; v[q * 4 + 3] = x.w;
+    mx = fmaxf(mx, fmaxf(fmaxf(x.x, x.y), fmaxf(x.z, x.w)));
+  }
+  if (TPR == 64) mx = wave_max(mx); else mx = block_max(mx, sh);
   float sum = 0.f;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) sum += __expf(s[i] + (cb ? cb[i] : 0.f) - mx);
-  sum = block_sum(sum, sh);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { v[q] = __expf(v[q] - mx); sum += v[q]; }
+  if (TPR == 64) sum = wave_sum(sum); else sum = block_sum(sum, sh);
   const float inv = 1.f / sum;
+  if (!live) return;
   act_t* p = P + row * ldp;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) p[i] = f2a(__expf(s[i] + (cb ? cb[i] : 0.f) - mx) * inv);
-  for (int i = N + threadIdx.x; i < ldp && i < N + 8; i += blockDim.x) p[i] = 0;   // zero the key padding (ldp = pad8(N))
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = (q * TPR + t) * 4;
+    if (c < N) *reinterpret_cast<uint2*>(p + c) = make_uint2(pack2a(v[q * 4] * inv, v[q * 4 + 1] * inv), pack2a(v[q * 4 + 2] * inv, v[q * 4 + 3] * inv));
+    else if (c < ldp) *reinterpret_cast<uint2*>(p + c) = make_uint2(0u, 0u);      // zero the key padding (ldp = pad8(N))
+  }
 }
 
 // dS = P * (dP - sum_j dP_j P_j) * scale ; P bf16, dP fp32 -> dS bf16
@@ -483,7 +524,7 @@ int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
                      (const act_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial,
                      P, C, G, rpb, ppb, 0);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, gamma, beta, stats, scale, shift, P, C, G,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(512), 0, st, partial, gamma, beta, stats, scale, shift, P, C, G,
                      nchunk, ppb, eps);
   if (y) hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, scale, shift, y, P, C, rpb, ppb, silu);
   return CHECK_LAUNCH();
@@ -497,7 +538,7 @@ int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* 
   gn_geom(P, C, nt, rpb, nchunk, ppb);
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x, dy,
                      scale, shift, stats, partial, P, C, G, rpb, ppb, silu);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, partial, stats, k0, k1, P, C, G, nchunk);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(512), 0, st, partial, stats, k0, k1, P, C, G, nchunk);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, dy, scale, shift, k0, k1, add, dx, P, C,
                      rpb, ppb, silu);
   return CHECK_LAUNCH();
@@ -512,8 +553,12 @@ int dmx_layernorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
 
 int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long rows, int N, long long lds, long long ldp,
                     int rows_per_bias, hipStream_t st) {
-  hipLaunchKernelGGL(softmax_kernel, dim3((unsigned)rows), dim3(N >= 1024 ? 256 : 64), 0, st, S, P, colbias, N, lds, ldp,
-                     rows_per_bias < 1 ? 1 : rows_per_bias);
+  if ((N & 3) || (lds & 3) || (ldp & 3) || N > 4096) return DMX_ERR_SHAPE;
+  const int rpb = rows_per_bias < 1 ? 1 : rows_per_bias;
+  if (N <= 1024)
+    hipLaunchKernelGGL(softmax_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, colbias, rows, N, lds, ldp, rpb);
+  else
+    hipLaunchKernelGGL(softmax_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, S, P, colbias, rows, N, lds, ldp, rpb);
   return CHECK_LAUNCH();
 }
 int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,

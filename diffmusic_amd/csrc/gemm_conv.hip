@@ -16,6 +16,72 @@ namespace {
 
 constexpr int BK = 64;  // bf16 elements per K-step (128 B per tile row)
 
+// Fused epilogue shared by both kernels: lane holds n = n0 + j*16 + 4*lq + {0..3} for pixel row m = m0 + i*16 + lr.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lr, int lq,
+                                              long long coff, int HqWq) {
+  const int flags = p.flags;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int b = m / HqWq, rem = m - b * HqWq;
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const long long orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + lq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (flags & EPI_MASK) {
+        const uint2 xr = *reinterpret_cast<const uint2*>(p.X + coff + orow * p.ldx + n);
+        const float s = p.mask_slope;
+        v[0] *= (alo(xr.x) > 0.f) ? 1.f : s;
+        v[1] *= (ahi(xr.x) > 0.f) ? 1.f : s;
+        v[2] *= (alo(xr.y) > 0.f) ? 1.f : s;
+        v[3] *= (ahi(xr.y) > 0.f) ? 1.f : s;
+      }
+      if (flags & EPI_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_ROWBIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * p.N + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_RESID) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.R + coff + orow * p.ldr + n);
+        v[0] += alo(rr.x); v[1] += ahi(rr.x); v[2] += alo(rr.y); v[3] += ahi(rr.y);
+      }
+      const float al = p.alpha;
+      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+      if (flags & EPI_F32OUT) {
+        float* cp = reinterpret_cast<float*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const float4 o = *reinterpret_cast<const float4*>(cp);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        act_t* cp = reinterpret_cast<act_t*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const uint2 o = *reinterpret_cast<const uint2*>(cp);
+          v[0] += alo(o.x); v[1] += ahi(o.x); v[2] += alo(o.y); v[3] += ahi(o.y);
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        if (!(flags & EPI_NO_C)) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
+      }
+      if (flags & EPI_LRELU2) {
+        const float s = p.act_slope;
+        const float a0 = v[0] > 0.f ? v[0] : v[0] * s, a1 = v[1] > 0.f ? v[1] : v[1] * s;
+        const float a2 = v[2] > 0.f ? v[2] : v[2] * s, a3 = v[3] > 0.f ? v[3] : v[3] * s;
+        *reinterpret_cast<uint2*>(p.C2 + coff + orow * p.ldc2 + n) = make_uint2(pack2a(a0, a1), pack2a(a2, a3));
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   constexpr int NT = WM * WN * 64;
@@ -145,67 +211,142 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds n = n0 + 4*lq + {0..3} for pixel row m = .. + lr
-  const int flags = p.flags;
+  gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile kernel: 8 waves, 256 x {256,128} x 64 tile, both operands brought in by LDS-DMA
+// (buffer_load_dwordx4 ... lds): no VGPR staging, no ds_write.  Each wave-instruction fills 1 KiB =
+// 8 tile rows x 128 B; the LDS image is lane-linear, so the XOR swizzle that makes the ds_read_b128
+// fragment reads conflict-free is applied to the per-lane SOURCE chunk (lane l fetches logical chunk
+// (l&7)^(l>>3) of row l>>3).  Conv zero padding, M/N/K tails: the lane's buffer offset is sent out of
+// range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
+constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int A_ISS = BM / 8 / NW, B_ISS = BN / 8 / NW;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  static_assert(A_ISS >= 1 && B_ISS >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  short2* s_taps = reinterpret_cast<short2*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int z = blockIdx.y;
+  const int zo = z / p.Zi, zi = z - zo * p.Zi;
+  const act_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
+  const act_t* Wb = p.W + zo * p.sWo + zi * p.sWi;
+  const long long coff = zo * p.sCo + zi * p.sCi;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, OOB, 0x00020000);
+
+  if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
+
+  const int lrow = lane >> 3, cc = (lane & 7) ^ lrow;   // logical 16-B chunk this lane fetches
+  const int cpt = p.Ci >> 3;
+  const int HqWq = p.Hq * p.Wq;
+  unsigned a_boff[A_ISS];
+  int a_iy[A_ISS], a_ix[A_ISS];
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int m = tm * BM + wm * TM + i * 16 + lr;
-    if (m >= p.M) continue;
-    const int b = m / HqWq, rem = m - b * HqWq;
-    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-    const long long orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = tn * BN + wn * TN + j * 16 + lq * 4;
-      if (n >= p.N) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (flags & EPI_MASK) {
-        const uint2 xr = *reinterpret_cast<const uint2*>(p.X + coff + orow * p.ldx + n);
-        const float s = p.mask_slope;
-        v[0] *= (alo(xr.x) > 0.f) ? 1.f : s;
-        v[1] *= (ahi(xr.x) > 0.f) ? 1.f : s;
-        v[2] *= (alo(xr.y) > 0.f) ? 1.f : s;
-        v[3] *= (ahi(xr.y) > 0.f) ? 1.f : s;
-      }
-      if (flags & EPI_BIAS) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (flags & EPI_ROWBIAS) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * p.N + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-      }
-      if (flags & EPI_RESID) {
-        const uint2 rr = *reinterpret_cast<const uint2*>(p.R + coff + orow * p.ldr + n);
-        v[0] += alo(rr.x); v[1] += ahi(rr.x); v[2] += alo(rr.y); v[3] += ahi(rr.y);
-      }
-      const float al = p.alpha;
-      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
-      if (flags & EPI_F32OUT) {
-        float* cp = reinterpret_cast<float*>(p.C) + coff + orow * p.ldc + n;
-        if (flags & EPI_ACCUM) {
-          const float4 o = *reinterpret_cast<const float4*>(cp);
-          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-        }
-        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
-        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        act_t* cp = reinterpret_cast<act_t*>(p.C) + coff + orow * p.ldc + n;
-        if (flags & EPI_ACCUM) {
-          const uint2 o = *reinterpret_cast<const uint2*>(cp);
-          v[0] += alo(o.x); v[1] += ahi(o.x); v[2] += alo(o.y); v[3] += ahi(o.y);
-        }
-        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
-        if (!(flags & EPI_NO_C)) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
-      }
-      if (flags & EPI_LRELU2) {
-        const float s = p.act_slope;
-        const float a0 = v[0] > 0.f ? v[0] : v[0] * s, a1 = v[1] > 0.f ? v[1] : v[1] * s;
-        const float a2 = v[2] > 0.f ? v[2] : v[2] * s, a3 = v[3] > 0.f ? v[3] : v[3] * s;
-        *reinterpret_cast<uint2*>(p.C2 + coff + orow * p.ldc2 + n) = make_uint2(pack2a(a0, a1), pack2a(a2, a3));
-      }
+  for (int i = 0; i < A_ISS; ++i) {
+    const int m = tm * BM + (i * NW + wave) * 8 + lrow;
+    if (m < p.M) {
+      const int b = m / HqWq, rem = m - b * HqWq;
+      const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+      a_boff[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * (unsigned)p.lda * 2u;
+      a_iy[i] = qy * p.sy;
+      a_ix[i] = qx * p.sx;
+    } else {
+      a_boff[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;
     }
   }
+  unsigned w_off[B_ISS];
+#pragma unroll
+  for (int i = 0; i < B_ISS; ++i) {
+    const int n = tn * BN + (i * NW + wave) * 8 + lrow;
+    w_off[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u : OOB;
+  }
+  __syncthreads();
+
+  const int kchunks = p.K >> 3;
+  auto issue = [&](int ks, int stage) {
+    const int kc = ks * 8 + cc;
+    const int tap = kc / cpt;
+    const unsigned cin2 = (unsigned)(kc - tap * cpt) << 4;      // byte offset of the chunk inside the pixel
+    const bool kval = kc < kchunks;
+    const short2 t = s_taps[tap & (DMX_MAX_TAPS - 1)];
+    char* sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int i = 0; i < A_ISS; ++i) {
+      const int iy = a_iy[i] + t.x, ix = a_ix[i] + t.y;
+      const bool ok = kval && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      const unsigned voff = ok ? a_boff[i] + (unsigned)(iy * p.Wi + ix) * (unsigned)p.lda * 2u + cin2 : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_ISS; ++i) {
+      const unsigned voff = (kval && w_off[i] != OOB) ? w_off[i] + ((unsigned)kc << 4) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  const int wm = wave / WN, wn = wave - wm * WN;
+  const int lr = lane & 15, lq = lane >> 4;
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + BK - 1) / BK;
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+    const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
+    const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int sw = ((kk * 4 + lq) ^ (lr & 7)) << 4;
+      frag8_t wf[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const frag8_t*>(sb + j * 16 * 128 + sw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const frag8_t af = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(wf[j], af, acc[i][j]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_glds(const GemmDesc& d, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN>), grid, dim3(NT), SMEM, stream, d);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -226,12 +367,78 @@ int launch_cfg(const GemmDesc& d, hipStream_t stream) {
 
 }  // namespace
 
+// ---- optional per-launch profiling (bench.py roofline leg): HIP events around every GEMM launch on its stream
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, Z, taps, flags; };
+bool g_prof = false;
+std::vector<ProfRec> g_prof_recs;
+int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
+  static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
+  // operand spans must stay below 2 GiB for the 32-bit buffer offsets of the LDS-DMA kernels
+  const bool span_ok = (long long)d.M * d.lda < (1ll << 29) && (long long)d.N * d.ldw < (1ll << 29) && d.sy == 1 && d.Z >= 1;
+  if (!legacy && span_ok && d.M >= 2048 && d.N % 128 == 0) {
+    // pick the tile that minimises (rounds over the 256 CUs) x (time per block); efficiencies measured on MI355X
+    auto cost = [&](int bm, int bn, int slots, double eff) {
+      const double blocks = (double)cdiv(d.M, bm) * cdiv(d.N, bn) * d.Z;
+      const double rounds = ceil(blocks / slots);
+      return rounds * (bm / 128.0) * (bn / 128.0) * (slots / 256.0) / eff;
+    };
+    const double cA = d.N % 256 == 0 ? cost(256, 256, 256, 0.95) : 1e30;
+    const double cB = cost(256, 128, 256, 0.82);
+    const double cC = cost(128, 128, 512, 0.68);
+    if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4>(d, stream);
+    if (cB <= cC) return launch_glds<256, 128, 4, 2>(d, stream);
+  }
+  if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
+  if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
+  return launch_cfg<128, 32, 4, 1>(d, stream);
+}
+}  // namespace
+
+extern "C" void dmx_prof_begin(void) {
+  for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof_recs.clear();
+  g_prof = true;
+}
+// stops recording; returns the number of launches, total kernel milliseconds and algorithmic FLOPs (2*M*N*K*Z)
+extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
+  g_prof = false;
+  (void)hipDeviceSynchronize();
+  double ms = 0.0, fl = 0.0;
+  FILE* csv = getenv("DMX_PROF_CSV") ? fopen(getenv("DMX_PROF_CSV"), "w") : nullptr;
+  if (csv) fprintf(csv, "M,N,K,Z,taps,flags,ms,tflops\n");
+  for (auto& r : g_prof_recs) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
+    if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, t, t > 0 ? r.flops / t / 1e9 : 0.0);
+    fl += r.flops;
+    (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+  }
+  if (csv) fclose(csv);
+  const int n = (int)g_prof_recs.size();
+  g_prof_recs.clear();
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  return n;
+}
+
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   if (d.M <= 0 || d.N <= 0 || d.K <= 0) return DMX_ERR_SHAPE;
   if ((d.Ci & 7) || (d.N & 3) || (d.K & 7) || (d.lda & 7) || (d.ldw & 7) || (d.ldc & 3)) return DMX_ERR_SHAPE;
   if (d.ntaps < 1 || d.ntaps > DMX_MAX_TAPS || d.K != d.ntaps * d.Ci) return DMX_ERR_SHAPE;
   if (d.Z < 1 || d.Zi < 1) return DMX_ERR_SHAPE;
-  if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
-  if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
-  return launch_cfg<128, 32, 4, 1>(d, stream);
+  if (!g_prof) return launch_dispatch(d, stream);
+  ProfRec r;
+  (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
+  r.flops = 2.0 * d.M * (double)d.N * d.K * d.Z;
+  r.M = d.M; r.N = d.N; r.K = d.K; r.Z = d.Z; r.taps = d.ntaps; r.flags = d.flags;
+  (void)hipEventRecord(r.a, stream);
+  const int rc = launch_dispatch(d, stream);
+  (void)hipEventRecord(r.b, stream);
+  g_prof_recs.push_back(r);
+  return rc;
 }

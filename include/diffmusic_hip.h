@@ -157,6 +157,10 @@ int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, 
                    const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
                    float sigma, float rate, float eps_small, int global_norm, void* stream);
 
+/* ---- measurement hooks: HIP events around every implicit-GEMM launch (bench.py roofline leg) ---------- */
+void dmx_prof_begin(void);
+int dmx_prof_end(double* total_ms, double* total_flops); /* returns the number of launches recorded */
+
 /* ---- low-level test hook: one implicit-GEMM launch described by the internal descriptor --------*/
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
 

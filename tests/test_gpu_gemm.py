@@ -39,7 +39,10 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("B,T,Ci,Co,k,dil", [(2, 333, 64, 128, 3, 1), (1, 1000, 32, 32, 11, 5), (3, 257, 128, 64, 7, 3),
-                                             (1, 130, 8, 16, 7, 1), (2, 77, 512, 512, 3, 1)])
+                                             (1, 130, 8, 16, 7, 1), (2, 77, 512, 512, 3, 1),
+                                             # M >= 4096: LDS-DMA large-tile kernels (256x256 and 256x128)
+                                             (2, 2500, 128, 256, 7, 3), (2, 3001, 64, 128, 11, 5), (1, 5001, 512, 512, 3, 1),
+                                             (3, 1777, 40, 384, 3, 1)])
 def test_conv1d_dilated(B, T, Ci, Co, k, dil):
     from diffmusic_amd import _lib as L
     g = torch.Generator().manual_seed(0)

@@ -18,7 +18,7 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("B,T,slope,gtol", [(1, 40, 1.0, 2e-2), (3, 57, 1.0, 2e-2), (2, 40, 0.1, 0.25)])
+@pytest.mark.parametrize("B,T,slope,gtol", [(1, 40, 1.0, 6e-2), (3, 57, 1.0, 6e-2), (2, 40, 0.1, 0.12)])
 def test_hifigan_fwd_bwd_vs_oracle(B, T, slope, gtol):
     """slope=1.0 makes the net linear (pins every conv/dgrad/epilogue path at bf16 rounding level);
     slope=0.1 is the real net, where bf16 activations flip leaky-relu' masks of near-zero units, so the
