@@ -388,8 +388,8 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
       return rounds * (bm / 128.0) * (bn / 128.0) * (slots / 256.0) / eff;
     };
     const double cA = d.N % 256 == 0 ? cost(256, 256, 256, 0.95) : 1e30;
-    const double cB = cost(256, 128, 256, 0.82);
-    const double cC = cost(128, 128, 512, 0.68);
+    const double cB = cost(256, 128, 256, 0.70);
+    const double cC = cost(128, 128, 512, 0.66);
     if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4>(d, stream);
     if (cB <= cC) return launch_glds<256, 128, 4, 2>(d, stream);
   }

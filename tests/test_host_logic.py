@@ -1,0 +1,79 @@
+"""CPU: host-side logic of the product facade (no GPU calls): scheduler tables and timesteps against the
+oracle's DDIM parent, registries, randn_tensor, config composition, mask generation."""
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.cases import SCHED_CFG
+
+
+def test_scheduler_tables_match_oracle_parent():
+    from diffmusic_amd.schedulers import get_scheduler
+    from oracle.ddim import DDIMParent
+    ref = DDIMParent(**SCHED_CFG)
+    for name in ("ddim", "dps", "mpgd", "dsg", "diffmusic"):
+        s = get_scheduler(name)(operator=None, **SCHED_CFG)
+        assert torch.equal(s.alphas_cumprod, ref.alphas_cumprod)
+        for n in (50, 200, 500):
+            s.set_timesteps(n)
+            ref.set_timesteps(n)
+            assert s._timesteps_host == [int(t) for t in ref.timesteps]
+            t = s._timesteps_host[n // 2]
+            prev = t - 1000 // n
+            assert abs(s._get_variance(t, prev) - float(ref._get_variance(t, prev))) < 1e-7
+        assert s.order == 1 and s.init_noise_sigma == 1.0
+        x = torch.randn(2, 3)
+        assert s.scale_model_input(x, 5) is x
+    import inspect
+    params = inspect.signature(get_scheduler("dps").step).parameters
+    assert "eta" in params and "generator" in params and "measurement" in params and "supervised_space" in params
+
+
+def test_registries_follow_the_reference_names():
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd.pipelines import get_pipeline
+    from diffmusic_amd.inverse_problem import get_noiser, GaussianNoise
+    assert get_scheduler("dps").__name__ == "DPSScheduler"
+    assert get_pipeline("musicldm").__name__ == "MusicLDMPipeline"
+    assert isinstance(get_noiser("gaussian", 0.0), GaussianNoise)
+    for fn, bad in ((get_scheduler, "nope"), (get_pipeline, "nope"), (lambda n: get_noiser(n, 0.0), "nope")):
+        with pytest.raises(ValueError):
+            fn(bad)
+    with pytest.raises(NotImplementedError):
+        get_scheduler("ditto")
+
+
+def test_randn_tensor_matches_oracle_semantics():
+    from diffmusic_amd.torch_utils import randn_tensor
+    from oracle.rng import randn_tensor as ref
+    gens = lambda: [torch.Generator().manual_seed(k) for k in range(3)]
+    a = randn_tensor((3, 8, 5, 4), generator=gens(), device=torch.device("cpu"), dtype=torch.float32)
+    b = ref((3, 8, 5, 4), generator=gens(), device=torch.device("cpu"), dtype=torch.float32)
+    assert torch.equal(a, b)
+    one = randn_tensor((1, 8, 5, 4), generator=[torch.Generator().manual_seed(1)], device=torch.device("cpu"), dtype=torch.float32)
+    assert torch.equal(one, a[1:2])
+
+
+def test_config_composition_reads_reference_keys():
+    from diffmusic_amd.config import compose
+    c = compose("dps", overrides=["data=moises", "model=musicldm"])
+    assert c.name == "dps" and c.scheduler.eta == 0.0 and c.scheduler.ip_guidance_rate == 0.0005
+    assert c.model.scheduler.beta_schedule == "scaled_linear" and c.model.scheduler.steps_offset == 1
+    assert c.data.hop_length == 160 and c.inverse_problem.noise.sigma == 0.0
+    assert compose("dsg").scheduler.eta == 1.0 and compose("mpgd").scheduler.ip_guidance_rate == 0.005
+    assert compose("ddim", overrides=["model=audioldm2", "scheduler.eta=0.5"]).scheduler.eta == 0.5
+
+
+def test_mask_generation_matches_golden(golden_dir):
+    import os
+    from diffmusic_amd.inverse_problem.operator import MusicInpaintingOperator
+    fx = np.load(os.path.join(golden_dir, "operators.npz"))
+    gm = MusicInpaintingOperator.generate_mask
+    for kind in ("box", "periodic"):
+        op = MusicInpaintingOperator.__new__(MusicInpaintingOperator)
+        op.audio_length_in_s, op.sample_rate, op.mask_type = 10, 16000, kind
+        op.start_inpainting_s, op.end_inpainting_s, op.mask_percentage, op.mask_duration_s, op.interval_s = 2, 3, 0.3, 0.1, 1.0
+        assert np.array_equal(np.nonzero(gm(op)[0].numpy() == 0)[0], fx[f"mask_{kind}/zeros"])
+    torch.manual_seed(1234)
+    op.mask_type, op.mask_duration_s = "random", 0.5
+    assert np.array_equal(np.nonzero(gm(op)[0].numpy() == 0)[0], fx["mask_random_seed1234/zeros"])
