@@ -173,7 +173,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share, not the host's core count
             sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
+            print(f"[bench] timing the CPU oracle on {threads} threads (1 clip x 1 step) ...", file=sys.stderr, flush=True)
             sec = cpu_baseline(sd, threads)
+            print(f"[bench] CPU oracle: {sec:.1f} s", file=sys.stderr, flush=True)
             res["cpu_baseline"] = {"value": round(1.0 / (sec * B), 6), "unit": "steps/s (batch-8 equivalent, extrapolated from 1 clip)",
                                    "cores": threads, "kind": "port",
                                    "sample": f"1 clip x 1 DPS step (U-Net 2x fwd + guided step), fp32 eager torch + autograd, {sec:.1f} s"}
