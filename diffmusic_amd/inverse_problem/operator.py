@@ -279,17 +279,100 @@ class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
         return loss, dwav
 
 
+def _fir_fwd(x, x_len, h, out_len, orig, new, off):
+    B = x.shape[0]
+    y = torch.empty(B, out_len, dtype=torch.float32, device=x.device)
+    L.check(L.lib().dmx_fir_fwd(_p(x), x.stride(0), _p(h), _p(y), out_len, B, x_len, out_len, h.shape[-1], orig, new, off, _stream()),
+            "fir_fwd")
+    return y
+
+
+def _fir_bwd(dy, h, h_rev, in_len, full_len, orig, new, off):
+    """gradient w.r.t. the first in_len samples of a (B, full_len) input; the tail gets zero."""
+    B, out_len = dy.shape
+    d = torch.zeros(B, full_len, dtype=torch.float32, device=dy.device)
+    L.check(L.lib().dmx_fir_bwd(_p(dy), out_len, _p(h), _p(h_rev), _p(d), full_len, B, in_len, out_len, h.shape[-1], orig, new, off,
+                                _stream()), "fir_bwd")
+    return d
+
+
 class SuperResolutionOperator(_MelOperator):              # operator.py:174-205
+    """forward = torchaudio Resample(sample_rate -> sample_rate // scale) (sinc_interp_hann, width 6, rolloff 0.99);
+    transform = clamp(wav2mel) applied to the low-rate signal with the 16 kHz mel parameters."""
+
     def __init__(self, sample_rate, scale=10, noiser=None):
-        self.orig, self.new = sample_rate, sample_rate // scale
+        self.orig_freq, self.new_freq = sample_rate, sample_rate // scale
+        kern, self.width, self.orig, self.new = dsp.sinc_resample_kernel(self.orig_freq, self.new_freq)
+        self._kern_host = torch.from_numpy(np.ascontiguousarray(kern))
+        self._kern = None
         self._init_mel(16000)
         self.noiser = noiser
-        raise NotImplementedError("SuperResolutionOperator: polyphase resampler kernel lands in the next milestone")
+
+    def _k(self, device):
+        if self._kern is None or self._kern.device != device:
+            self._kern = self._kern_host.to(device)
+        return self._kern
+
+    def _out_len(self, n):
+        return int(math.ceil(self.new * n / self.orig))
+
+    def forward(self, data, **kwargs):
+        data = _as_f32_cuda(data)
+        y = _fir_fwd(data, data.shape[1], self._k(data.device), self._out_len(data.shape[1]), self.orig, self.new, self.width)
+        return self.noiser(y) if self.noiser is not None else y
+
+    def _a_fwd(self, wav, length):
+        self._in_len = length
+        return _fir_fwd(wav, length, self._k(wav.device), self._out_len(length), self.orig, self.new, self.width)
+
+    def _a_bwd(self, dy, full):
+        return _fir_bwd(dy, self._k(dy.device), None, self._in_len, full, self.orig, self.new, self.width)
 
 
 class MusicDereverberationOperator(_MelOperator):         # operator.py:208-250
-    def __init__(self, ir_length=800, decay_factor=0.85, noiser=None):
-        self.ir_length, self.decay_factor = ir_length, decay_factor
+    """forward = conv1d with a random impulse response.  The reference draws a NEW response from the global RNG on
+    every forward call (operator.py:244-246), so the measurement and every guidance step see different responses;
+    that is the default here too.  `fixed_ir=True` (extension) draws once and keeps it; `ir=` pins one call."""
+
+    def __init__(self, ir_length=800, decay_factor=0.85, noiser=None, fixed_ir=False):
+        self.ir_length, self.decay_factor, self.fixed_ir = ir_length, decay_factor, fixed_ir
         self._init_mel(16000)
         self.noiser = noiser
-        raise NotImplementedError("MusicDereverberationOperator: FIR kernel lands in the next milestone")
+        self._ir = None
+
+    def generate_impulse_response(self, ir_length=800, decay_factor=0.85):       # operator.py:238-242 (host, global RNG)
+        ir = torch.randn(ir_length)
+        ir = torch.cumsum(ir, dim=0) * decay_factor
+        ir /= ir.abs().max()
+        return ir.unsqueeze(0)
+
+    def _get_ir(self, device, ir=None):
+        if ir is None:
+            if self.fixed_ir and self._ir is not None:
+                ir = self._ir
+            else:
+                ir = self.generate_impulse_response(self.ir_length, self.decay_factor)
+                if self.fixed_ir:
+                    self._ir = ir
+        h = ir.reshape(1, -1).to(device=device, dtype=torch.float32).contiguous()
+        return h, torch.flip(h, dims=[1]).contiguous()
+
+    def forward(self, data, ir=None, **kwargs):
+        data = _as_f32_cuda(data)
+        h, _ = self._get_ir(data.device, ir)
+        n = h.shape[1]
+        y = _fir_fwd(data, data.shape[1], h, data.shape[1] + 2 * (n // 2) - n + 1, 1, 1, n // 2)
+        return self.noiser(y) if self.noiser is not None else y
+
+    def guidance(self, wav, length, measurement, supervised_space, ir=None):
+        self._h, self._hrev = self._get_ir(wav.device, ir)
+        return super().guidance(wav, length, measurement, supervised_space)
+
+    def _a_fwd(self, wav, length):
+        n = self._h.shape[1]
+        self._in_len = length
+        return _fir_fwd(wav, length, self._h, length + 2 * (n // 2) - n + 1, 1, 1, n // 2)
+
+    def _a_bwd(self, dy, full):
+        n = self._h.shape[1]
+        return _fir_bwd(dy, self._h, self._hrev, self._in_len, full, 1, 1, n // 2)

@@ -103,11 +103,11 @@ class GuidedDDIMScheduler:
         return t, a_t, a_p, sigma
 
     # ---- HIP guidance sweep: x0 -> vae -> vocoder -> A -> loss ; and back
-    def _guidance(self, x0, measurement, vae, vocoder, length, supervised_space):
+    def _guidance(self, x0, measurement, vae, vocoder, length, supervised_space, op_kwargs=None):
         zs = 1.0 / vae.config.scaling_factor
         mel = vae.decode_hip(x0, z_scale=zs, keep_state=True)              # (B, H, W) fp16
         wav = vocoder.forward(mel)                                         # (B, Lfull) fp32
-        loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space)
+        loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space, **(op_kwargs or {}))
         inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
         L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
                 "grad_normalize")
@@ -147,7 +147,8 @@ class GuidedDDIMScheduler:
         if self.mode == "ddim":
             loss = torch.tensor([t])
         else:
-            loss, g0, inv_scale = self._guidance(x0, measurement, vae, vocoder, original_waveform_length, supervised_space)
+            loss, g0, inv_scale = self._guidance(x0, measurement, vae, vocoder, original_waveform_length, supervised_space,
+                                                 kwargs.get("op_kwargs"))
             if self.mode in ("dsg", "diffmusic"):
                 sn = kwargs.get("sample_noise")
                 if sn is None:

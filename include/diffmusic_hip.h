@@ -142,6 +142,15 @@ int dmx_l2_loss(const float* ref, long long ref_stride, const float* pred, float
 /* per-clip x *= target/max|x| ; inv_scale[b] = max|x|/target  (keeps the fp16 backward sweep in range) */
 int dmx_grad_normalize(float* x, float* inv_scale, int batch, long long n, float target, void* stream);
 
+/* Polyphase / dense FIR (fp32): out[j*new + p] = sum_t h[p][t] * in[j*orig + t - off], zero outside [0, Lin).
+ * Replaces torchaudio Resample in SuperResolutionOperator.forward (operator.py:203-205; h = sinc-hann kernel (new, taps),
+ * off = width) and F.conv1d in MusicDereverberationOperator.forward (operator.py:247-249; orig = new = 1, off = taps/2). */
+int dmx_fir_fwd(const float* in, long long in_stride, const float* h, float* out, long long out_stride, int batch, int Lin, int Lout,
+                int taps, int orig, int new_, int off, void* stream);
+/* transpose of dmx_fir_fwd (gradient w.r.t. `in`); h_rev = time-reversed taps, required only for the dense 1:1 case */
+int dmx_fir_bwd(const float* dout, long long dout_stride, const float* h, const float* h_rev, float* din, long long din_stride, int batch,
+                int Lin, int Lout, int taps, int orig, int new_, int off, void* stream);
+
 /* ---- scheduler arithmetic (diffmusic/schedulers/scheduling_{ddim,dps,mpgd,dsg,diffmusic}.py step bodies) -------------- */
 #define DMX_SCHED_DDIM 0
 #define DMX_SCHED_DPS 1

@@ -47,13 +47,23 @@ def _ops(task):
     if task == "phase_retrieval":
         return (P.PhaseRetrievalOperator(noiser=P.get_noiser("gaussian", 0.0)),
                 O.PhaseRetrievalOperator(noiser=O.get_noiser("gaussian", 0.0)))
+    if task == "super_resolution":
+        return (P.SuperResolutionOperator(16000, 2, noiser=P.get_noiser("gaussian", 0.0)),
+                O.SuperResolutionOperator(16000, 2, noiser=O.get_noiser("gaussian", 0.0)))
+    if task == "super_resolution4":
+        return (P.SuperResolutionOperator(16000, 4, noiser=P.get_noiser("gaussian", 0.0)),
+                O.SuperResolutionOperator(16000, 4, noiser=O.get_noiser("gaussian", 0.0)))
+    if task == "music_dereverberation":
+        return (P.MusicDereverberationOperator(500, 0.99, noiser=P.get_noiser("gaussian", 0.0)),
+                O.MusicDereverberationOperator(500, 0.99, noiser=O.get_noiser("gaussian", 0.0)))
     return P.IdentityOperator(16000), O.IdentityOperator(16000)
 
 
 CASES = [("dps", "music_inpainting", 0.0, 5e-4, "mel_spectrogram", 501), ("dps", "music_inpainting", 0.0, 5e-4, "wav_form", 996),
          ("mpgd", "music_inpainting", 0.0, 5e-3, "mel_spectrogram", 251), ("dsg", "phase_retrieval", 1.0, 0.08, "mel_spectrogram", 501),
          ("diffmusic", "music_inpainting", 1.0, 0.08, "mel_spectrogram", 501), ("dps", "identity", 0.5, 5e-4, "mel_spectrogram", 101),
-         ("ddim", "identity", 0.0, 0.0, "mel_spectrogram", 501)]
+         ("ddim", "identity", 0.0, 0.0, "mel_spectrogram", 501), ("mpgd", "super_resolution4", 0.0, 5e-3, "mel_spectrogram", 501),
+         ("dps", "super_resolution", 0.0, 5e-4, "wav_form", 251), ("dps", "music_dereverberation", 0.0, 5e-4, "mel_spectrogram", 501)]
 
 
 @pytest.mark.parametrize("name,task,eta,rate,space,t", CASES)
@@ -65,8 +75,12 @@ def test_teacher_forced_step(nets, name, task, eta, rate, space, t):
     B = 2
     g = torch.Generator().manual_seed(77)
     clean = 0.3 * torch.sin(torch.arange(LEN) * 0.05)[None] * torch.tensor([[1.0], [0.6]]) + 0.05 * torch.randn(B, LEN, generator=g)
-    y_ref = rop.forward(clean)
-    y = op.forward(clean.cuda())
+    opk = {}
+    if task == "music_dereverberation":       # pin the impulse response (the reference redraws it on every call)
+        ir = rop.generate_impulse_response(500, 0.99)
+        opk = dict(ir=ir)
+    y_ref = rop.forward(clean, **opk)
+    y = op.forward(clean.cuda(), **opk)
     assert _rel(y, y_ref) < 1e-4, "operator.forward"
     x = torch.randn(B, 8, H, W, generator=g)
     e = torch.randn(B, 8, H, W, generator=g)
@@ -78,10 +92,10 @@ def test_teacher_forced_step(nets, name, task, eta, rate, space, t):
     rs.set_timesteps(200)
     kw = dict(eta=eta, ip_guidance_rate=rate, original_waveform_length=LEN, supervised_space=space)
     noise_kw = dict(sample_noise=z.cuda()) if name in ("dsg", "diffmusic") else dict(variance_noise=z.cuda() if eta > 0 else None)
-    out = sched.step(e.cuda(), t, x.cuda(), measurement=y, vae=vae, vocoder=voc, **kw, **noise_kw)
+    out = sched.step(e.cuda(), t, x.cuda(), measurement=y, vae=vae, vocoder=voc, op_kwargs=opk, **kw, **noise_kw)
     torch.cuda.synchronize()
     rnoise = dict(sample_noise=z) if name in ("dsg", "diffmusic") else dict(variance_noise=z if eta > 0 else None)
-    ro = rs.step(e, t, x, measurement=y_ref, vae=rvae, vocoder=rvoc, **kw, **rnoise)
+    ro = rs.step(e, t, x, measurement=y_ref, vae=rvae, vocoder=rvoc, op_kwargs=opk, **kw, **rnoise)
     rp, rl = _rel(out.prev_sample, ro.prev_sample), None
     assert _rel(out.pred_original_sample, ro.pred_original_sample) < 1e-4 or name == "mpgd"
     msg = f"{name}/{task}/{space}: prev {rp:.2e}"
