@@ -29,7 +29,7 @@ class UNetConfig(C.Structure):
                 ("block_out_channels", C.c_int * MAX_STAGES), ("layers_per_block", C.c_int),
                 ("attention_heads", C.c_int), ("norm_num_groups", C.c_int),
                 ("down_attn", C.c_int * MAX_STAGES), ("up_attn", C.c_int * MAX_STAGES),
-                ("class_embed_dim", C.c_int)]
+                ("class_embed_dim", C.c_int), ("num_attn_per_layer", C.c_int), ("attn_cross_dims", C.c_int * 4)]
 
 
 class GemmDesc(C.Structure):
@@ -80,6 +80,9 @@ _SIGS = {
     "dmx_unet_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dmx_unet_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_unet_fwd_ctx": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_unet_workspace_bytes_ctx": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -82,13 +82,22 @@ int dmx_vae_decode_bwd(dmx_model* m, const uint16_t* dmel, float z_scale, float*
   return dmx_vae_bwd_impl(m->impl, dmel, z_scale, dz, ST(stream));
 }
 
-size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w) { return dmx_unet_ws_impl(m->impl, batch, h, w); }
+size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w) { return dmx_unet_ws_impl(m->impl, batch, h, w, 0, 0); }
+size_t dmx_unet_workspace_bytes_ctx(dmx_model* m, int batch, int h, int w, int n0, int n1) { return dmx_unet_ws_impl(m->impl, batch, h, w, n0, n1); }
 int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h, int w,
                  void* ws, size_t ws_bytes, void* stream) {
   int rc = check(m, DMX_MODEL_UNET);
   if (rc) return rc;
   if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
-  return dmx_unet_fwd_impl(m->impl, x, t, class_labels, eps, batch, h, w, ws, ws_bytes, ST(stream));
+  return dmx_unet_fwd_impl(m->impl, x, t, class_labels, eps, batch, h, w, ws, ws_bytes, ST(stream), nullptr, 0, nullptr, 0, nullptr);
+}
+int dmx_unet_fwd_ctx(dmx_model* m, const float* x, const float* t, const float* class_labels, const float* ctx0, int n0,
+                     const float* ctx1, int n1, const float* bias1, float* eps, int batch, int h, int w, void* ws, size_t ws_bytes,
+                     void* stream) {
+  int rc = check(m, DMX_MODEL_UNET);
+  if (rc) return rc;
+  if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
+  return dmx_unet_fwd_impl(m->impl, x, t, class_labels, eps, batch, h, w, ws, ws_bytes, ST(stream), ctx0, n0, ctx1, n1, bias1);
 }
 
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream) {

@@ -32,6 +32,6 @@ int dmx_vae_fwd_impl(Model* m, const float* z, float zs, act_t* mel, float* mel3
                      hipStream_t st);
 int dmx_vae_bwd_impl(Model* m, const act_t* dmel, float zs, float* dz, hipStream_t st);
 Model* dmx_make_unet(const dmx_unet_config* c);
-size_t dmx_unet_ws_impl(Model* m, int B, int h, int w);
+size_t dmx_unet_ws_impl(Model* m, int B, int h, int w, int n0, int n1);
 int dmx_unet_fwd_impl(Model* m, const float* x, const float* t, const float* cls, float* eps, int B, int h, int w, void* ws, size_t wsb,
-                      hipStream_t st);
+                      hipStream_t st, const float* c0, int n0, const float* c1, int n1, const float* bias1);

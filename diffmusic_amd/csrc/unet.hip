@@ -58,15 +58,16 @@ struct Transformer2D {
   ConvLayer proj_in, proj_out, ff1, ff2;
   LnParams ln1, ln2, ln3;
   AttnLayer attn1, attn2;
+  int cross = 0;   // > 0: attn2 attends an external context of that width
   void build(ParamStore& ps, const std::string& pre, int ch, int heads, int cross_dim, int groups) {
-    C = ch;
+    C = ch; cross = cross_dim > 0 ? cross_dim : 0;
     norm.build(ps, pre + ".norm", ch, groups, 1e-6f);
     proj_in = make_conv2d(ps, pre + ".proj_in", ch, ch, 1, 1, 0, false);
     const std::string tb = pre + ".transformer_blocks.0";
     ln1.build(ps, tb + ".norm1", ch);
     attn1.build(ps, tb + ".attn1", ch, ch, heads);
     ln2.build(ps, tb + ".norm2", ch);
-    attn2.build(ps, tb + ".attn2", ch, cross_dim, heads);
+    attn2.build(ps, tb + ".attn2", ch, cross > 0 ? cross : ch, heads);
     ln3.build(ps, tb + ".norm3", ch);
     ff1 = make_linear(ps, tb + ".ff.net.0.proj", ch, ch * 8, true, false);
     ff2 = make_linear(ps, tb + ".ff.net.2", ch * 4, ch, true, false);
@@ -80,7 +81,8 @@ struct Transformer2D {
     return DMX_OK;
   }
   // x (B,H,W,C) -> out (B,H,W,C); out may not alias x
-  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W) const {
+  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* ctx = nullptr, int Nc = 0,
+          const float* colbias = nullptr) const {
     Arena& A = *cx.arena;
     const int N = H * W;
     const size_t mk = A.mark();
@@ -94,7 +96,8 @@ struct Transformer2D {
     CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
     CTRY(attn1.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));
     CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
-    CTRY(attn2.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));     // encoder_hidden_states=None -> self-attention
+    if (cross > 0) CTRY(attn2.fwd(cx, l, ctx, Nc, hbuf, B, N, colbias));
+    else CTRY(attn2.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));   // encoder_hidden_states=None -> self-attention
     CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
     {
       const size_t mk2 = A.mark();
@@ -126,15 +129,22 @@ struct UNet : Model {
   };
   std::vector<Block> down, up;
   Resnet2D mid_r0, mid_r1;
-  Transformer2D mid_attn;
   float* gn_partial = nullptr;
-  int temb_ch = 0, tdim = 0;
+  int temb_ch = 0, tdim = 0, napl = 1;
+  int cross_dims[4] = {-1, 0, 0, 0};
+  std::vector<Transformer2D> mid_attns;
+  // per-call contexts (fp16 copies) for cross-attention transformers
+  const act_t* ctx_ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+  int ctx_n[4] = {0, 0, 0, 0};
+  const float* ctx_bias[4] = {nullptr, nullptr, nullptr, nullptr};
 
   explicit UNet(const dmx_unet_config& c) : cfg(c) {
     kind = DMX_MODEL_UNET;
     const int nb = c.num_blocks, G = c.norm_num_groups, hd = c.attention_heads;
     const int* boc = c.block_out_channels;
     tdim = boc[0] * 4;
+    napl = c.num_attn_per_layer > 0 ? c.num_attn_per_layer : 1;
+    for (int q = 0; q < 4; ++q) cross_dims[q] = q < napl ? c.attn_cross_dims[q] : 0;
     temb_ch = c.class_embed_dim > 0 ? tdim * 2 : tdim;
     time1 = make_linear(ps, "time_embedding.linear_1", boc[0], tdim, true, false);
     time2 = make_linear(ps, "time_embedding.linear_2", tdim, tdim, true, false);
@@ -148,17 +158,20 @@ struct UNet : Model {
       b.ch = out; b.has_attn = c.down_attn[i] != 0; b.has_sampler = i != nb - 1;
       const std::string pre = "down_blocks." + std::to_string(i);
       b.res.resize(c.layers_per_block);
-      if (b.has_attn) b.attn.resize(c.layers_per_block);
+      if (b.has_attn) b.attn.resize(c.layers_per_block * napl);
       for (int j = 0; j < c.layers_per_block; ++j) {
         b.res[j].build(ps, pre + ".resnets." + std::to_string(j), j == 0 ? cin : out, out, temb_ch, G, 1e-5f, false);
-        if (b.has_attn) b.attn[j].build(ps, pre + ".attentions." + std::to_string(j), out, hd, out, G);
+        if (b.has_attn)
+          for (int q = 0; q < napl; ++q)
+            b.attn[j * napl + q].build(ps, pre + ".attentions." + std::to_string(j * napl + q), out, hd, cross_dims[q], G);
       }
       if (b.has_sampler) b.sampler = make_conv2d(ps, pre + ".downsamplers.0.conv", out, out, 3, 2, 1, false);
       down.push_back(b);
     }
     const int cm = boc[nb - 1];
     mid_r0.build(ps, "mid_block.resnets.0", cm, cm, temb_ch, G, 1e-5f, false);
-    mid_attn.build(ps, "mid_block.attentions.0", cm, hd, cm, G);
+    mid_attns.resize(napl);
+    for (int q = 0; q < napl; ++q) mid_attns[q].build(ps, "mid_block.attentions." + std::to_string(q), cm, hd, cross_dims[q], G);
     mid_r1.build(ps, "mid_block.resnets.1", cm, cm, temb_ch, G, 1e-5f, false);
     out = boc[nb - 1];
     for (int i = 0; i < nb; ++i) {
@@ -170,12 +183,14 @@ struct UNet : Model {
       const std::string pre = "up_blocks." + std::to_string(i);
       const int n = c.layers_per_block + 1;
       b.res.resize(n);
-      if (b.has_attn) b.attn.resize(n);
+      if (b.has_attn) b.attn.resize(n * napl);
       for (int j = 0; j < n; ++j) {
         const int skip = j == n - 1 ? cin : out;
         const int rin = j == 0 ? prev : out;
         b.res[j].build(ps, pre + ".resnets." + std::to_string(j), rin + skip, out, temb_ch, G, 1e-5f, false);
-        if (b.has_attn) b.attn[j].build(ps, pre + ".attentions." + std::to_string(j), out, hd, out, G);
+        if (b.has_attn)
+          for (int q = 0; q < napl; ++q)
+            b.attn[j * napl + q].build(ps, pre + ".attentions." + std::to_string(j * napl + q), out, hd, cross_dims[q], G);
       }
       if (b.has_sampler) b.sampler = make_conv2d(ps, pre + ".upsamplers.0.conv", out, out, 3, 1, 1, false);
       up.push_back(b);
@@ -196,13 +211,29 @@ struct UNet : Model {
         for (auto& a : b.attn) CTRY(a.pack(ps, st));
         if (b.has_sampler) CTRY(pack_layer(ps, b.sampler, st));
       }
-    CTRY(mid_r0.pack(ps, st)); CTRY(mid_attn.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
+    CTRY(mid_r0.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
+    for (auto& a : mid_attns) CTRY(a.pack(ps, st));
     return DMX_OK;
   }
 
   struct Skip { act_t* p; int H, W, C; };
 
-  int forward(const float* x, const float* t, const float* cls, float* eps, int B, int H0, int W0, void* ws, size_t wsb, hipStream_t st) {
+  // runs the napl transformers of one layer in sequence: in -> out (both (B,H,W,ch)); tmp is a scratch of the same size
+  int run_attn(Ctx& cx, const Transformer2D* tf, const act_t* in, act_t* out, act_t* tmp, int B, int H, int W) {
+    const act_t* src = in;
+    int kctx = 0;
+    for (int q = 0; q < napl; ++q) {
+      act_t* dst = ((napl - 1 - q) & 1) ? tmp : out;          // last one lands in `out`
+      const bool cross = tf[q].cross > 0;
+      CTRY(tf[q].fwd(cx, src, dst, B, H, W, cross ? ctx_ptr[kctx] : nullptr, cross ? ctx_n[kctx] : 0, cross ? ctx_bias[kctx] : nullptr));
+      if (cross) ++kctx;
+      src = dst;
+    }
+    return DMX_OK;
+  }
+
+  int forward(const float* x, const float* t, const float* cls, float* eps, int B, int H0, int W0, void* ws, size_t wsb, hipStream_t st,
+              const float* c0 = nullptr, int n0 = 0, const float* c1 = nullptr, int n1 = 0, const float* bias1 = nullptr) {
     if (B > 64) { dmx_set_error("unet: batch > 64 unsupported"); return DMX_ERR_SHAPE; }
     dry = (ws == nullptr);
     arena.reset(ws, dry ? (size_t)-1 : wsb);
@@ -211,6 +242,20 @@ struct UNet : Model {
     const int nb = cfg.num_blocks;
     const int* boc = cfg.block_out_channels;
     Epi e;
+    // ---- cross-attention contexts -> fp16
+    {
+      const float* cin[2] = {c0, c1};
+      const int cn[2] = {n0, n1};
+      int k = 0;
+      for (int q = 0; q < napl; ++q) {
+        if (cross_dims[q] <= 0) continue;
+        if (k >= 2 || (cn[k] & 3) || cn[k] <= 0 || (!dry && !cin[k])) { dmx_set_error("unet: context %d missing or length not a multiple of 4", k); return DMX_ERR_SHAPE; }
+        act_t* c16 = A.bf((size_t)B * cn[k] * cross_dims[q]);
+        CRUN(dmx_f32_to_bf16(cin[k], c16, (long long)B * cn[k] * cross_dims[q], 1.f, st));
+        ctx_ptr[k] = c16; ctx_n[k] = cn[k]; ctx_bias[k] = (k == 1) ? bias1 : nullptr;
+        ++k;
+      }
+    }
     // ---- embeddings: silu([time_emb | class_emb])
     act_t* semb = A.bf((size_t)B * temb_ch);
     {
@@ -250,8 +295,9 @@ struct UNet : Model {
         act_t* y = A.bf((size_t)B * H * W * b.ch);
         if (b.has_attn) {
           act_t* y2 = A.bf((size_t)B * H * W * b.ch);   // resnet output (transient but simpler to keep)
+          act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * b.ch) : nullptr;
           CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr));
-          CTRY(b.attn[j].fwd(cx, y2, y, B, H, W));
+          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
         } else {
           CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr));
         }
@@ -272,8 +318,9 @@ struct UNet : Model {
       act_t* y0 = A.bf((size_t)B * H * W * cm);
       act_t* y1 = A.bf((size_t)B * H * W * cm);
       act_t* y2 = A.bf((size_t)B * H * W * cm);
+      act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * cm) : nullptr;
       CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr));
-      CTRY(mid_attn.fwd(cx, y0, y1, B, H, W));
+      CTRY(run_attn(cx, mid_attns.data(), y0, y1, y3, B, H, W));
       CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr));
       cur = y2;
     }
@@ -288,13 +335,14 @@ struct UNet : Model {
         const int cc = curC + s.C;
         act_t* y = A.bf((size_t)B * H * W * b.ch);
         act_t* y2 = b.has_attn ? A.bf((size_t)B * H * W * b.ch) : nullptr;
+        act_t* y3 = (b.has_attn && napl > 1) ? A.bf((size_t)B * H * W * b.ch) : nullptr;
         const size_t mk = A.mark();
         act_t* cat = A.bf((size_t)B * H * W * cc);
         CRUN(dmx_copy_channels(cur, cat, (long long)B * H * W, curC, curC, cc, 0, 0, st));
         CRUN(dmx_copy_channels(s.p, cat, (long long)B * H * W, s.C, s.C, cc, 0, curC, st));
         if (b.has_attn) {
           CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr));
-          CTRY(b.attn[j].fwd(cx, y2, y, B, H, W));
+          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
         } else {
           CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr));
         }
@@ -328,14 +376,14 @@ struct UNet : Model {
 };
 
 Model* dmx_make_unet(const dmx_unet_config* c) { return new UNet(*c); }
-size_t dmx_unet_ws_impl(Model* m, int B, int h, int w) {
+size_t dmx_unet_ws_impl(Model* m, int B, int h, int w, int n0, int n1) {
   UNet* u = static_cast<UNet*>(m);
   u->arena.peak = 0;
-  u->forward(nullptr, nullptr, nullptr, nullptr, B, h, w, nullptr, 0, nullptr);
+  u->forward(nullptr, nullptr, nullptr, nullptr, B, h, w, nullptr, 0, nullptr, nullptr, n0, nullptr, n1, nullptr);
   u->dry = false;
   return u->arena.peak + 256;
 }
 int dmx_unet_fwd_impl(Model* m, const float* x, const float* t, const float* cls, float* eps, int B, int h, int w, void* ws, size_t wsb,
-                      hipStream_t st) {
-  return static_cast<UNet*>(m)->forward(x, t, cls, eps, B, h, w, ws, wsb, st);
+                      hipStream_t st, const float* c0, int n0, const float* c1, int n1, const float* bias1) {
+  return static_cast<UNet*>(m)->forward(x, t, cls, eps, B, h, w, ws, wsb, st, c0, n0, c1, n1, bias1);
 }

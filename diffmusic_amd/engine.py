@@ -14,7 +14,9 @@ VAE_DEFAULT = dict(latent_channels=8, out_channels=1, block_out_channels=[128, 2
                    norm_num_groups=32, scaling_factor=0.9227914214134216, eps=1e-6)
 UNET_MUSICLDM_DEFAULT = dict(in_channels=8, out_channels=8, block_out_channels=[128, 256, 384, 640],
                              layers_per_block=2, attention_heads=8, norm_num_groups=32,
-                             down_attn=[0, 1, 1, 1], up_attn=[1, 1, 1, 0], class_embed_dim=512)
+                             down_attn=[0, 1, 1, 1], up_attn=[1, 1, 1, 0], class_embed_dim=512, attn_cross_dims=[0])
+# AudioLDM2UNet2DConditionModel: three transformers per layer (self, GPT-2 states 768, T5 states 1024), no class embedding
+UNET_AUDIOLDM2_DEFAULT = dict(UNET_MUSICLDM_DEFAULT, class_embed_dim=0, attn_cross_dims=[0, 768, 1024])
 
 
 def _stream():
@@ -208,17 +210,41 @@ class UNetEngine(_Engine):
         _fill(c.down_attn, cfg["down_attn"])
         _fill(c.up_attn, cfg["up_attn"])
         c.class_embed_dim = cfg["class_embed_dim"]
+        acd = [int(d or 0) for d in cfg.get("attn_cross_dims", [0])]
+        c.num_attn_per_layer = len(acd)
+        _fill(c.attn_cross_dims, acd)
+        self._n_ctx = sum(1 for d in acd if d > 0)
         super().__init__(L.lib().dmx_unet_create(C.byref(c)), cfg, device)
 
-    def forward(self, x, t, class_labels):
-        """x (B, C, h, w) fp32, t (B,) fp32, class_labels (B, class_embed_dim) fp32 -> eps fp32 like x."""
+    def forward(self, x, t, class_labels=None, encoder_hidden_states=None, encoder_hidden_states_1=None,
+                encoder_attention_mask_1=None):
+        """x (B, C, h, w) fp32, t (B,) fp32, class_labels (B, class_embed_dim) fp32 -> eps fp32 like x.
+        AudioLDM2: encoder_hidden_states (B, 8, 768), encoder_hidden_states_1 (B, L, 1024) + mask (B, L)."""
         assert x.dtype == torch.float32 and x.is_cuda and x.is_contiguous()
         B, _, h, w = x.shape
-        t = t.to(device=x.device, dtype=torch.float32).reshape(-1).expand(B).contiguous()
-        class_labels = class_labels.to(device=x.device, dtype=torch.float32).contiguous()
+        dev = x.device
+        t = t.to(device=dev, dtype=torch.float32).reshape(-1).expand(B).contiguous()
+        if class_labels is not None:
+            class_labels = class_labels.to(device=dev, dtype=torch.float32).contiguous()
         lib = L.lib()
-        ws = self._workspace(("u", B, h, w), lib.dmx_unet_workspace_bytes(self._h, B, h, w))
-        eps = torch.empty(B, self.cfg["out_channels"], h, w, dtype=torch.float32, device=x.device)
-        L.check(lib.dmx_unet_fwd(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(eps), B, h, w, _ptr(ws), ws.numel(),
-                                 _stream()), "unet_fwd")
+        eps = torch.empty(B, self.cfg["out_channels"], h, w, dtype=torch.float32, device=dev)
+        if self._n_ctx == 0:
+            ws = self._workspace(("u", B, h, w), lib.dmx_unet_workspace_bytes(self._h, B, h, w))
+            L.check(lib.dmx_unet_fwd(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(eps), B, h, w, _ptr(ws), ws.numel(),
+                                     _stream()), "unet_fwd")
+            return eps
+        c0 = encoder_hidden_states.to(device=dev, dtype=torch.float32).contiguous()
+        c1 = encoder_hidden_states_1.to(device=dev, dtype=torch.float32)
+        m1 = encoder_attention_mask_1
+        m1 = torch.ones(c1.shape[:2], device=dev) if m1 is None else m1.to(device=dev, dtype=torch.float32)
+        pad = (-c1.shape[1]) % 4                     # key count must be a multiple of 4: pad with masked-out tokens
+        if pad:
+            c1 = torch.nn.functional.pad(c1, (0, 0, 0, pad))
+            m1 = torch.nn.functional.pad(m1, (0, pad))
+        c1 = c1.contiguous()
+        bias1 = ((1.0 - m1) * -10000.0).contiguous()
+        n0, n1 = c0.shape[1], c1.shape[1]
+        ws = self._workspace(("u", B, h, w, n0, n1), lib.dmx_unet_workspace_bytes_ctx(self._h, B, h, w, n0, n1))
+        L.check(lib.dmx_unet_fwd_ctx(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(c0), n0, _ptr(c1), n1, _ptr(bias1), _ptr(eps),
+                                     B, h, w, _ptr(ws), ws.numel(), _stream()), "unet_fwd_ctx")
         return eps

@@ -1,0 +1,46 @@
+"""AudioLDM2 pipeline facade (reference: diffmusic/pipelines/plpeline_audioldm2.py:924-1254).  Same loop as MusicLDM
+(the reference's two loops differ only in conditioning, :1147-1154, and in the default guidance_scale 3.5, :930);
+the U-Net attends two contexts: `generated_prompt_embeds` (B, 8, 768) from GPT-2 and `prompt_embeds` (B, L, 1024) from
+T5 with `attention_mask`.  The text / projection / GPT-2 front end is out of scope: pass the embeddings directly, as the
+reference signature allows."""
+import torch
+
+from ..engine import UNET_AUDIOLDM2_DEFAULT
+from .pipeline_musicldm import MusicLDMPipeline
+
+
+class AudioLDM2Pipeline(MusicLDMPipeline):
+    default_guidance_scale = 3.5
+    unet_default_config = UNET_AUDIOLDM2_DEFAULT
+
+    def _prepare_cond(self, prompt_embeds, negative_prompt_embeds, n_per, do_cfg, device, generated_prompt_embeds=None,
+                      negative_generated_prompt_embeds=None, attention_mask=None, negative_attention_mask=None, **_):
+        if generated_prompt_embeds is None:
+            raise NotImplementedError("the GPT-2 front end is out of scope: pass generated_prompt_embeds (B, 8, 768)")
+
+        def rep(x):
+            return None if x is None else x.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
+        pe, ge, am = rep(prompt_embeds), rep(generated_prompt_embeds), rep(attention_mask)
+        if am is None:
+            am = torch.ones(pe.shape[:2], device=device)
+        if do_cfg:                                                   # plpeline_audioldm2.py:640-668: [negative | positive]
+            npe = rep(negative_prompt_embeds) if negative_prompt_embeds is not None else pe
+            nge = rep(negative_generated_prompt_embeds) if negative_generated_prompt_embeds is not None else ge
+            nam = rep(negative_attention_mask) if negative_attention_mask is not None else am
+            pe, ge, am = torch.cat([npe, pe]), torch.cat([nge, ge]), torch.cat([nam, am])
+        return dict(class_labels=None, encoder_hidden_states=ge, encoder_hidden_states_1=pe, encoder_attention_mask_1=am)
+
+    def __call__(self, prompt=None, transcription=None, audio_length_in_s=None, num_inference_steps=200, guidance_scale=3.5,
+                 negative_prompt=None, num_waveforms_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
+                 negative_prompt_embeds=None, generated_prompt_embeds=None, negative_generated_prompt_embeds=None,
+                 attention_mask=None, negative_attention_mask=None, max_new_tokens=None, **kw):
+        self._extra_cond = dict(generated_prompt_embeds=generated_prompt_embeds,
+                                negative_generated_prompt_embeds=negative_generated_prompt_embeds,
+                                attention_mask=attention_mask, negative_attention_mask=negative_attention_mask)
+        try:
+            return super().__call__(prompt=prompt, audio_length_in_s=audio_length_in_s, num_inference_steps=num_inference_steps,
+                                    guidance_scale=guidance_scale, negative_prompt=negative_prompt,
+                                    num_waveforms_per_prompt=num_waveforms_per_prompt, eta=eta, generator=generator, latents=latents,
+                                    prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, **kw)
+        finally:
+            self._extra_cond = {}

@@ -42,7 +42,8 @@ class MusicLDMPipeline:
     def from_pretrained(cls, repo_id, torch_dtype=None, seed=0, unet_config=None, vae_config=None, vocoder_config=None, **kw):
         """`repo_id` may be a local directory with {unet,vae,vocoder}/*.safetensors in the upstream naming, or
         "synthetic" (seeded variance-preserving weights of the benchmark architecture; no checkpoint exists offline)."""
-        unet, vae, voc = UNetEngine(unet_config), VaeDecoderEngine(vae_config), HifiGanEngine(vocoder_config)
+        unet = UNetEngine(unet_config if unet_config is not None else cls.unet_default_config)
+        vae, voc = VaeDecoderEngine(vae_config), HifiGanEngine(vocoder_config)
         if os.path.isdir(str(repo_id)):
             from safetensors.torch import load_file
             for eng, sub in ((unet, "unet"), (vae, "vae"), (voc, "vocoder")):
@@ -103,16 +104,34 @@ class MusicLDMPipeline:
         fig.savefig(path)
         plt.close(fig)
 
-    def _unet_eps(self, latents, t_host, prompt_embeds2, guidance_scale, do_cfg):
+    default_guidance_scale = 2.0
+    unet_default_config = None
+
+    def _prepare_cond(self, prompt_embeds, negative_prompt_embeds, n_per, do_cfg, device, **extra):
+        """MusicLDM: CLAP text embedding (B, 512) as class_labels; [uncond | text] on the CFG batch (:243-248)."""
+        pe = prompt_embeds.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
+        if do_cfg:
+            ne = negative_prompt_embeds if negative_prompt_embeds is not None else prompt_embeds   # prompt="" -> cond == uncond
+            ne = ne.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
+            pe = torch.cat([ne, pe], dim=0)
+        return dict(class_labels=pe)
+
+    def _cond_is_symmetric(self, cond, B):
+        return all(torch.equal(v[:B], v[B:]) for v in cond.values() if v is not None)
+
+    def _unet_eps(self, latents, t_host, cond, guidance_scale, do_cfg):
         """U-Net on the (2B) CFG batch + combine (pipeline_musicldm.py:692-708), all HIP."""
+        if not isinstance(cond, dict):
+            cond = dict(class_labels=cond)
         x = latents.to(torch.float32).contiguous()
         B = x.shape[0]
         if not do_cfg:
-            return self.unet.forward(x, torch.full((B,), float(t_host)), prompt_embeds2)
-        if self.dedupe_cfg and torch.equal(prompt_embeds2[:B], prompt_embeds2[B:]):
-            return self.unet.forward(x, torch.full((B,), float(t_host)), prompt_embeds2[:B])     # uncond + s*(text-uncond) == text
+            return self.unet.forward(x, torch.full((B,), float(t_host)), **cond)
+        if self.dedupe_cfg and self._cond_is_symmetric(cond, B):
+            half = {k: (v[:B] if v is not None else None) for k, v in cond.items()}
+            return self.unet.forward(x, torch.full((B,), float(t_host)), **half)                   # uncond + s*(text-uncond) == text
         x2 = torch.cat([x, x], dim=0)
-        eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host)), prompt_embeds2)
+        eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host)), **cond)
         out = torch.empty_like(x)
         L.check(L.lib().dmx_sched_cfg_combine(C.c_void_p(eps2.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(), float(guidance_scale),
                                               _stream()), "cfg_combine")
@@ -141,12 +160,8 @@ class MusicLDMPipeline:
         device = self.device
         batch_size = prompt_embeds.shape[0]
         do_cfg = guidance_scale > 1.0
-        pe = prompt_embeds.to(device=device, dtype=torch.float32)
-        pe = pe.repeat_interleave(num_waveforms_per_prompt, dim=0)
-        if do_cfg:
-            ne = negative_prompt_embeds if negative_prompt_embeds is not None else prompt_embeds     # prompt="" -> cond == uncond
-            ne = ne.to(device=device, dtype=torch.float32).repeat_interleave(num_waveforms_per_prompt, dim=0)
-            pe = torch.cat([ne, pe], dim=0)                                                          # [uncond | text]  (:243-248)
+        pe = self._prepare_cond(prompt_embeds, negative_prompt_embeds, num_waveforms_per_prompt, do_cfg, device,
+                                **getattr(self, "_extra_cond", {}))
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = list(self.scheduler._timesteps_host)
         nlat = self.unet.cfg["in_channels"]

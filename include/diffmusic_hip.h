@@ -69,6 +69,9 @@ typedef struct dmx_unet_config {
   int down_attn[DMX_MAX_STAGES]; /* 0,1,1,1 */
   int up_attn[DMX_MAX_STAGES];   /* 1,1,1,0 */
   int class_embed_dim;           /* 512 (simple_projection, concat) ; 0 = none */
+  int num_attn_per_layer;        /* MusicLDM 1 ; AudioLDM2 3 (one Transformer2DModel per cross_attention_dim entry) */
+  int attn_cross_dims[4];        /* per transformer: <= 0 self-attention (context None), > 0 cross-attention width;
+                                    the k-th positive entry attends context k (AudioLDM2: {0, 768, 1024}) */
 } dmx_unet_config;
 
 int dmx_abi_version(void);
@@ -112,6 +115,12 @@ size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w);
 /* x (B, in_ch, h, w) fp32 NCHW, t (B) fp32 timesteps, class_labels (B, class_embed_dim) fp32 -> eps (B, out_ch, h, w) fp32 */
 int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h,
                  int w, void* ws, size_t ws_bytes, void* stream);
+/* AudioLDM2 variant (plpeline_audioldm2.py:1147-1154): ctx0 (B, n0, d0) = generated_prompt_embeds (GPT-2), ctx1 (B, n1, d1) =
+ * prompt_embeds (T5), bias1 (B, n1) additive score bias = (1 - attention_mask) * -10000; all fp32; n0, n1 multiples of 4 */
+int dmx_unet_fwd_ctx(dmx_model* m, const float* x, const float* t, const float* class_labels, const float* ctx0, int n0,
+                     const float* ctx1, int n1, const float* bias1, float* eps, int batch, int h, int w, void* ws,
+                     size_t ws_bytes, void* stream);
+size_t dmx_unet_workspace_bytes_ctx(dmx_model* m, int batch, int h, int w, int n0, int n1);
 
 /* ---- STFT / mel measurement path (fp32): replaces torchaudio MelSpectrogram + AmplitudeToDB / MelScale and
  * torch.stft as used by the operators (diffmusic/inverse_problem/operator.py:23-33,143-147,162-170) and the

@@ -260,6 +260,9 @@ class BasicTransformerBlock(nn.Module):
 class Transformer2DModel(nn.Module):
     def __init__(self, ch, heads, dim_head, cross_dim, groups):
         super().__init__()
+        self.external_ctx = cross_dim is not None and cross_dim > 0
+        if not cross_dim or cross_dim <= 0:
+            cross_dim = ch
         self.norm = nn.GroupNorm(groups, ch, eps=1e-6)
         self.proj_in = nn.Conv2d(ch, ch, 1)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, dim_head, cross_dim)])
@@ -275,20 +278,35 @@ class Transformer2DModel(nn.Module):
         return self.proj_out(h) + r
 
 
+def _run_attn(attentions, i, napl, x, ctxs):
+    """AudioLDM2-style: napl transformers per resnet layer; a transformer whose cross dim is an external width consumes the
+    next (context, additive_mask) pair of `ctxs`; the others are (double) self-attention (context None)."""
+    k = 0
+    for q in range(napl):
+        t = attentions[i * napl + q]
+        if t.external_ctx:
+            x = t(x, ctxs[k][0], ctxs[k][1])
+            k += 1
+        else:
+            x = t(x, None)
+    return x
+
+
 class _DownBlock(nn.Module):
-    def __init__(self, cin, cout, n, temb, groups, heads, cross_dim, add_down, attn):
+    def __init__(self, cin, cout, n, temb, groups, heads, cross_dims, add_down, attn):
         super().__init__()
+        self.napl = len(cross_dims)
         self.resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb, groups) for i in range(n)])
-        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, cross_dim, groups)
-                                         for _ in range(n)]) if attn else None
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, cd, groups)
+                                         for _ in range(n) for cd in cross_dims]) if attn else None
         self.downsamplers = nn.ModuleList([Downsample2D(cout)]) if add_down else None
 
-    def forward(self, x, temb, ctx=None):
+    def forward(self, x, temb, ctxs=None):
         outs = []
         for i, r in enumerate(self.resnets):
             x = r(x, temb)
             if self.attentions is not None:
-                x = self.attentions[i](x, ctx)
+                x = _run_attn(self.attentions, i, self.napl, x, ctxs)
             outs.append(x)
         if self.downsamplers is not None:
             x = self.downsamplers[0](x)
@@ -297,35 +315,37 @@ class _DownBlock(nn.Module):
 
 
 class _UpBlock(nn.Module):
-    def __init__(self, cin, cout, prev, n, temb, groups, heads, cross_dim, add_up, attn):
+    def __init__(self, cin, cout, prev, n, temb, groups, heads, cross_dims, add_up, attn):
         super().__init__()
+        self.napl = len(cross_dims)
         self.resnets = nn.ModuleList()
         for i in range(n):
             skip = cin if i == n - 1 else cout
             rin = prev if i == 0 else cout
             self.resnets.append(ResnetBlock2D(rin + skip, cout, temb, groups))
-        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, cross_dim, groups)
-                                         for _ in range(n)]) if attn else None
+        self.attentions = nn.ModuleList([Transformer2DModel(cout, heads, cout // heads, cd, groups)
+                                         for _ in range(n) for cd in cross_dims]) if attn else None
         self.upsamplers = nn.ModuleList([Upsample2D(cout)]) if add_up else None
 
-    def forward(self, x, skips, temb, ctx=None, up_size=None):
+    def forward(self, x, skips, temb, ctxs=None, up_size=None):
         for i, r in enumerate(self.resnets):
             x = r(torch.cat([x, skips.pop()], dim=1), temb)
             if self.attentions is not None:
-                x = self.attentions[i](x, ctx)
+                x = _run_attn(self.attentions, i, self.napl, x, ctxs)
         if self.upsamplers is not None:
             x = self.upsamplers[0](x, up_size)
         return x
 
 
 class _UNetMid(nn.Module):
-    def __init__(self, ch, temb, groups, heads, cross_dim):
+    def __init__(self, ch, temb, groups, heads, cross_dims):
         super().__init__()
+        self.napl = len(cross_dims)
         self.resnets = nn.ModuleList([ResnetBlock2D(ch, ch, temb, groups), ResnetBlock2D(ch, ch, temb, groups)])
-        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, cross_dim, groups)])
+        self.attentions = nn.ModuleList([Transformer2DModel(ch, heads, ch // heads, cd, groups) for cd in cross_dims])
 
-    def forward(self, x, temb, ctx=None):
-        return self.resnets[1](self.attentions[0](self.resnets[0](x, temb), ctx), temb)
+    def forward(self, x, temb, ctxs=None):
+        return self.resnets[1](_run_attn(self.attentions, 0, self.napl, self.resnets[0](x, temb), ctxs), temb)
 
 
 def timestep_embedding(t, dim=128, flip_sin_to_cos=True, shift=0.0, max_period=10000):
@@ -349,13 +369,14 @@ class _TimestepEmbedding(nn.Module):
 
 
 class UNetMusicLDM(nn.Module):
+    # also serves as the AudioLDM2 U-Net: attn_cross_dims=(None, 768, 1024), class_embed_dim=0
     """UNet2DConditionModel with class_embed_type='simple_projection', class_embeddings_concat,
     encoder_hidden_states=None (so attn2 is self-attention), conv proj_in/out."""
 
     def __init__(self, in_channels=8, out_channels=8, block_out_channels=(128, 256, 384, 640),
                  layers_per_block=2, attention_heads=8, norm_num_groups=32,
                  down_attn=(False, True, True, True), up_attn=(True, True, True, False),
-                 class_embed_dim=512, cross_attention_dim=None):
+                 class_embed_dim=512, attn_cross_dims=(None,)):
         super().__init__()
         boc = list(block_out_channels)
         self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels,
@@ -365,10 +386,11 @@ class UNetMusicLDM(nn.Module):
                                       class_embed_dim=class_embed_dim, sample_size=128)
         tdim = boc[0] * 4
         self.time_embedding = _TimestepEmbedding(boc[0], tdim)
-        self.class_embedding = nn.Linear(class_embed_dim, tdim)
-        temb = tdim * 2
+        self.class_embedding = nn.Linear(class_embed_dim, tdim) if class_embed_dim else None
+        temb = tdim * 2 if class_embed_dim else tdim
         g, hd = norm_num_groups, attention_heads
-        cd = cross_attention_dim or boc
+        acd = [c if c and c > 0 else None for c in attn_cross_dims]
+        cd = [acd] * len(boc)
         self.conv_in = nn.Conv2d(in_channels, boc[0], 3, padding=1)
         self.down_blocks = nn.ModuleList()
         out = boc[0]
@@ -388,11 +410,24 @@ class UNetMusicLDM(nn.Module):
         self.conv_norm_out = nn.GroupNorm(g, boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], out_channels, 3, padding=1)
 
-    def forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None, **kw):
+    def forward(self, sample, timestep, encoder_hidden_states=None, class_labels=None, encoder_hidden_states_1=None,
+                encoder_attention_mask_1=None, **kw):
+        """MusicLDM: class_labels only.  AudioLDM2 (plpeline_audioldm2.py:1147-1154): encoder_hidden_states = GPT-2 states
+        (B,8,768), encoder_hidden_states_1 = T5 states (B,L,1024) with encoder_attention_mask_1 (B,L)."""
         B = sample.shape[0]
         t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(B)
         emb = self.time_embedding(timestep_embedding(t, self.config.block_out_channels[0]).to(sample.dtype))
-        emb = torch.cat([emb, self.class_embedding(class_labels.to(sample.dtype))], dim=-1)
+        if self.class_embedding is not None:
+            emb = torch.cat([emb, self.class_embedding(class_labels.to(sample.dtype))], dim=-1)
+        ctxs = []
+        if encoder_hidden_states is not None:
+            ctxs.append((encoder_hidden_states, None))
+        if encoder_hidden_states_1 is not None:
+            bias = None
+            if encoder_attention_mask_1 is not None:
+                bias = ((1 - encoder_attention_mask_1.to(sample.dtype)) * -10000.0)[:, None, None, :]
+            ctxs.append((encoder_hidden_states_1, bias))
+        encoder_hidden_states = ctxs
         x = self.conv_in(sample)
         skips = [x]
         for blk in self.down_blocks:

@@ -30,3 +30,30 @@ def test_unet_fwd_vs_oracle(B, h, w, t):
     print("rel eps", _rel(out.cpu(), oref), float(oref.std()))
     assert oref.std() > 0.05
     assert _rel(out.cpu(), oref) < 1e-2
+
+
+A2 = dict(SMALL, class_embed_dim=0, attn_cross_dims=[0, 48, 64])
+
+
+def test_audioldm2_unet_fwd_vs_oracle():
+    """Three transformers per layer: self, cross (8 GPT-2 tokens), cross with key mask (T5 tokens, L=10 -> padded to 12)."""
+    from diffmusic_amd.engine import UNetEngine
+    from oracle.models import UNetMusicLDM
+    eng = UNetEngine(A2)
+    sd = eng.synth_state_dict(seed=4)
+    eng.load_state_dict(sd)
+    ref = UNetMusicLDM(**{k: v for k, v in A2.items() if k != "attn_cross_dims"}, attn_cross_dims=(None, 48, 64))
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(8)
+    B = 2
+    x = torch.randn(B, 8, 26, 16, generator=g)
+    c0 = torch.randn(B, 8, 48, generator=g)
+    c1 = torch.randn(B, 10, 64, generator=g)
+    mask = torch.ones(B, 10)
+    mask[1, 7:] = 0
+    out = eng.forward(x.cuda(), torch.full((B,), 501.0), None, c0.cuda(), c1.cuda(), mask.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        oref = ref(x, 501, encoder_hidden_states=c0, encoder_hidden_states_1=c1, encoder_attention_mask_1=mask)[0]
+    print("rel eps (audioldm2)", _rel(out.cpu(), oref))
+    assert _rel(out.cpu(), oref) < 1e-2
