@@ -82,6 +82,143 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-staged epilogue for fp16 outputs.  The MFMA accumulator layout gives a lane 4 channels of one pixel
+// (8-byte pieces, 32-byte runs per row); written straight to HBM that is 1/4 of a cache line per row and the
+// epilogue ran at ~2 TB/s, 35-65 % of a HiFi-GAN layer's time.  Here every tensor the epilogue touches (mask
+// source X, residual R, previous C, outputs C and C2) moves between HBM and a wave-private LDS tile in full
+// row segments (16 B per lane, TN*2-byte contiguous runs = whole cache lines) and is exchanged with the
+// accumulator layout through LDS.  Rows are handled in chunks of CH <= 64 to fit 8 waves in the stage buffers.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
+                                                  long long coff, int HqWq, char* wl) {
+  constexpr int TM = FM * 16;
+  constexpr int CH = TM < 64 ? TM : 64;
+  constexpr int IB = CH / 16;
+  constexpr int TNB = FN * 32;            // bytes per tile row
+  constexpr int PITCH = TNB + 16;
+  constexpr int CPR = TNB / 16;           // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;           // rows per wave-instruction in the row-major phase
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rr = lane / CPR, cch = lane - rr * CPR;
+  long long* tab = reinterpret_cast<long long*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range)
+  int* tabb = reinterpret_cast<int*>(wl + CH * PITCH + CH * 8);      // batch image per tile row
+  const int flags = p.flags;
+  const int ncol = n0 + cch * 8;
+  const bool col_ok = ncol < p.N;
+#define DMX_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#pragma unroll
+  for (int h = 0; h < FM / IB; ++h) {
+    if (lq == 0) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const int m = m0 + (h * IB + ii) * 16 + lr;
+        long long orow = -1;
+        int b = 0;
+        if (m < p.M) {
+          b = m / HqWq;
+          const int rem = m - b * HqWq;
+          const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+          orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+        }
+        tab[ii * 16 + lr] = orow;
+        tabb[ii * 16 + lr] = b;
+      }
+    }
+    DMX_LDS_SYNC();
+    // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`
+    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
+#pragma unroll
+      for (int r0 = 0; r0 < CH; r0 += RPI) {
+        const int row = r0 + rr;
+        const long long orow = tab[row];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (orow >= 0 && col_ok) v = *reinterpret_cast<const uint4*>(G + coff + orow * ld + ncol);
+        *reinterpret_cast<uint4*>(wl + row * PITCH + cch * 16) = v;
+      }
+      DMX_LDS_SYNC();
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const uint2 q = *reinterpret_cast<const uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2);
+          f(acc[h * IB + ii][j], alo(q.x), ahi(q.x), alo(q.y), ahi(q.y));
+        }
+      DMX_LDS_SYNC();
+    };
+    auto stage_out = [&](act_t* G, int ld, auto&& f) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          float o[4];
+          f(acc[h * IB + ii][j], o);
+          *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
+        }
+      DMX_LDS_SYNC();
+#pragma unroll
+      for (int r0 = 0; r0 < CH; r0 += RPI) {
+        const int row = r0 + rr;
+        const long long orow = tab[row];
+        const uint4 v = *reinterpret_cast<const uint4*>(wl + row * PITCH + cch * 16);
+        if (orow >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + orow * ld + ncol) = v;
+      }
+      DMX_LDS_SYNC();
+    };
+    if (flags & EPI_MASK) {
+      const float sl = p.mask_slope;
+      stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+        a[0] *= x0 > 0.f ? 1.f : sl; a[1] *= x1 > 0.f ? 1.f : sl; a[2] *= x2 > 0.f ? 1.f : sl; a[3] *= x3 > 0.f ? 1.f : sl;
+      });
+    }
+    if (flags & (EPI_BIAS | EPI_ROWBIAS)) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + j * 16 + lq * 4;
+          if (n >= p.N) continue;
+          f32x4& a = acc[h * IB + ii][j];
+          if (flags & EPI_BIAS) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+          }
+          if (flags & EPI_ROWBIAS) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)tabb[ii * 16 + lr] * p.N + n);
+            a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+          }
+        }
+    }
+    if (flags & EPI_RESID)
+      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+    {
+      const float al = p.alpha;
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] *= al; a[1] *= al; a[2] *= al; a[3] *= al; }
+    }
+    if (flags & EPI_ACCUM)
+      stage_in(reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+    if (flags & EPI_TANH) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
+    }
+    if (!(flags & EPI_NO_C))
+      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+    if (flags & EPI_LRELU2) {
+      const float sl = p.act_slope;
+      stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
+        o[0] = a[0] > 0.f ? a[0] : a[0] * sl; o[1] = a[1] > 0.f ? a[1] : a[1] * sl;
+        o[2] = a[2] > 0.f ? a[2] : a[2] * sl; o[3] = a[3] > 0.f ? a[3] : a[3] * sl;
+      });
+    }
+  }
+#undef DMX_LDS_SYNC
+}
+
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   constexpr int NT = WM * WN * 64;
@@ -211,7 +348,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
     __syncthreads();
   }
 
-  gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+  if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
+    gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+  } else {
+    constexpr int EPI_CH = (FM * 16 < 64 ? FM * 16 : 64);
+    constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
+    static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
+    gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,8 +366,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 // (l&7)^(l>>3) of row l>>3).  Conv zero padding, M/N/K tails: the lane's buffer offset is sent out of
 // range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
 constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
+#ifdef DMX_NOLOAD
+constexpr unsigned NUMREC = 0u;          // timing-only build: every LDS-DMA is range-checked away (zeros)
+#else
+constexpr unsigned NUMREC = OOB;
+#endif
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -233,19 +382,28 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   static_assert(A_ISS >= 1 && B_ISS >= 1, "tile too small");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  short2* s_taps = reinterpret_cast<short2*>(smem + 2 * STAGE);
+  short2* s_taps = reinterpret_cast<short2*>(smem + NSTAGE * STAGE);
+  constexpr int PER = A_ISS + B_ISS;              // LDS-DMA instructions per thread per stage
+  constexpr int KEEP = (NSTAGE - 2) * PER;        // loads allowed in flight when the next tile must have landed
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous run of logical tiles so the
+  // N-tiles of one M-tile and neighbouring M-tiles (shared A rows / halos, same weights) hit the same L2.  Bijective for any grid.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int z = blockIdx.y;
   const int zo = z / p.Zi, zi = z - zo * p.Zi;
   const act_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
   const act_t* Wb = p.W + zo * p.sWo + zi * p.sWi;
   const long long coff = zo * p.sCo + zi * p.sCi;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, NUMREC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, NUMREC, 0x00020000);
 
   if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
 
@@ -276,8 +434,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   __syncthreads();
 
   const int kchunks = p.K >> 3;
+  // K order: with Ci % 64 == 0 a K-step is one (tap, 64-channel group); walk the taps innermost so the ~(BM + halo)
+  // input rows of a channel group are re-read from L2 by consecutive K-steps instead of once per pass over all channels
+  const bool tap_inner = (p.Ci & 63) == 0 && p.ntaps > 1;
+  const int cgroups = p.Ci >> 6;
   auto issue = [&](int ks, int stage) {
-    const int kc = ks * 8 + cc;
+    int kc;
+    if (tap_inner) {
+      const int cg = ks / p.ntaps, tp = ks - cg * p.ntaps;
+      kc = (cg < cgroups) ? tp * cpt + cg * 8 + cc : kchunks;   // past the end -> out of range
+    } else {
+      kc = ks * 8 + cc;
+    }
     const int tap = kc / cpt;
     const unsigned cin2 = (unsigned)(kc - tap * cpt) << 4;      // byte offset of the chunk inside the pixel
     const bool kval = kc < kchunks;
@@ -305,13 +473,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // NSTAGE-deep ring: tiles ks+1 .. ks+NSTAGE-1 are in flight while tile ks is consumed.  Every iteration issues
+  // exactly one stage (past the end the offsets are out of range -> zero fill, no memory traffic), so the vmcnt
+  // counts are compile-time constants; the raw s_barrier keeps the younger loads in flight across it.
   const int nk = (p.K + BK - 1) / BK;
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+  __builtin_amdgcn_s_barrier();
+  int cur = 0, nxt = NSTAGE - 1;
   for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+#if !defined(DMX_ISSUE_MID) && !defined(DMX_NOISSUE)
+    issue(ks + NSTAGE - 1, nxt);
+#endif
     const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
     const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
 #pragma unroll
@@ -320,32 +494,74 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
       frag8_t wf[FN];
 #pragma unroll
       for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const frag8_t*>(sb + j * 16 * 128 + sw);
+#ifdef DMX_PREFETCH_A
+      frag8_t af[FM];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
+#endif
+#ifdef DMX_SETPRIO
+      __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const frag8_t af = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
+#ifdef DMX_PREFETCH_A
+        const frag8_t a = af[i];
+#else
+        const frag8_t a = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
+#endif
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(wf[j], af, acc[i][j]);
+#ifdef DMX_NOMFMA
+        asm volatile("" ::"v"(a));
+        if (i == 0) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[j]));
+        }
+#else
+        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(wf[j], a, acc[i][j]);
+#endif
       }
+#ifdef DMX_SETPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(DMX_ISSUE_MID) && !defined(DMX_NOISSUE)
+      if (kk == 0) issue(ks + NSTAGE - 1, nxt);
+#endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
+#ifndef DMX_NOBARRIER
+    __builtin_amdgcn_s_barrier();
+#endif
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
-  gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill tail ...
+  __builtin_amdgcn_s_barrier();                          // ... of every wave before the stage buffers are reused by the epilogue
+#ifdef DMX_NOEPI
+  if (p.alpha == 12345.f)
+#endif
+  if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
+    gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+  } else {
+    constexpr int EPI_CH = (FM * 16 < 64 ? FM * 16 : 64);
+    constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
+    static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
+    gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+  }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_glds(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
+  constexpr int SMEM = NSTAGE * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN>), grid, dim3(NT), SMEM, stream, d);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
@@ -390,8 +606,8 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     const double cA = d.N % 256 == 0 ? cost(256, 256, 256, 0.95) : 1e30;
     const double cB = cost(256, 128, 256, 0.70);
     const double cC = cost(128, 128, 512, 0.66);
-    if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4>(d, stream);
-    if (cB <= cC) return launch_glds<256, 128, 4, 2>(d, stream);
+    if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4, 2>(d, stream);
+    if (cB <= cC) return launch_glds<256, 128, 4, 2, 3>(d, stream);
   }
   if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
   if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
