@@ -114,3 +114,4 @@ struct GemmDesc {
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);
+bool dmx_prof_is_active();

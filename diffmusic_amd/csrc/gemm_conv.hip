@@ -609,11 +609,15 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4, 2>(d, stream);
     if (cB <= cC) return launch_glds<256, 128, 4, 2, 3>(d, stream);
   }
+  // small problems: 64x64 tiles so that at least ~1 block per CU exists (U-Net levels with 1k-4k pixels)
+  if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) return launch_cfg<64, 64, 2, 2>(d, stream);
   if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
   if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
   return launch_cfg<128, 32, 4, 1>(d, stream);
 }
 }  // namespace
+
+bool dmx_prof_is_active() { return g_prof; }
 
 extern "C" void dmx_prof_begin(void) {
   for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

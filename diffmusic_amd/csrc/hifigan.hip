@@ -7,6 +7,7 @@
 // each convolution consumed (its sign is the leaky-relu' mask; sign(lrelu(x)) == sign(x)), and the
 // tanh output.  Weights never receive gradients, so dgrad needs no saved conv inputs.
 #include "models.h"
+#include <cstdlib>
 
 struct HifiGan : Model {
   dmx_hifigan_config cfg;
@@ -23,6 +24,14 @@ struct HifiGan : Model {
   std::vector<act_t*> act_out;        // [stage] lrelu(stage output) (slope of the consumer)
   float* wav8 = nullptr;               // (B, Tout, 8) fp32 tanh output, channel 0 real
   bool have_tape = false;
+  // The nk resblock branches of a stage are independent until their outputs are averaged: they run on their own HIP
+  // streams so that the tail of one branch's launches (314 tiles on 256 CUs at M = 40 008) is filled by the others.
+  hipStream_t bstream[DMX_MAX_STAGES] = {};
+  std::vector<hipEvent_t> events;
+  size_t ev_next = 0;
+  bool want_multi = true;
+  hipEvent_t next_event() { hipEvent_t e = events[ev_next]; ev_next = (ev_next + 1) % events.size(); return e; }
+  bool multi() const { return want_multi && !dry && !dmx_prof_is_active() && nk > 1; }
 
   int idx(int s, int k, int d) const { return (s * nk + k) * nd + d; }
 
@@ -49,6 +58,14 @@ struct HifiGan : Model {
       }
     }
     conv_post = make_conv1d(ps, "conv_post", ch, 1, 7, 1, 3, true);
+    want_multi = getenv("DMX_SINGLE_STREAM") == nullptr;
+    for (int k = 1; k < nk; ++k) (void)hipStreamCreateWithFlags(&bstream[k], hipStreamNonBlocking);
+    events.resize(256);
+    for (auto& e : events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  }
+  ~HifiGan() override {
+    for (int k = 1; k < nk; ++k) if (bstream[k]) (void)hipStreamDestroy(bstream[k]);
+    for (auto& e : events) (void)hipEventDestroy(e);
   }
 
   int finalize(hipStream_t st) override {
@@ -98,35 +115,46 @@ struct HifiGan : Model {
         }
       const size_t mk = arena.mark();       // transients below are released per stage
       act_t* xs = arena.bf(n);
-      act_t* xA = arena.bf(n);
-      act_t* xB = arena.bf(n);
       act_t* sum = arena.bf(n);
+      act_t* xAB[DMX_MAX_STAGES][2];
+      for (int k = 0; k < nk; ++k) { xAB[k][0] = arena.bf(n); xAB[k][1] = arena.bf(n); }
       {
         Epi e; e.flags = EPI_LRELU2; e.act_slope = slope; e.C2 = xs_a[s];
         RUN(conv_fwd_1d(up, cur_act, xs, B, Tin, e, st));
       }
       const float next_slope = (s == ns - 1) ? 0.01f : slope;
+      const bool mt = multi();
+      hipEvent_t fin_prev = nullptr;
+      if (mt) {
+        hipEvent_t e0 = next_event();
+        (void)hipEventRecord(e0, st);
+        for (int k = 1; k < nk; ++k) (void)hipStreamWaitEvent(bstream[k], e0, 0);
+      }
       for (int k = 0; k < nk; ++k) {
+        hipStream_t sk = (mt && k > 0) ? bstream[k] : st;
         const act_t* x = xs;
         for (int d = 0; d < nd; ++d) {
           const int id = idx(s, k, d);
           {
             Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = ha[id];
-            RUN(conv_fwd_1d(c1[id], xa[id], ha[id], B, To, e, st));
+            RUN(conv_fwd_1d(c1[id], xa[id], ha[id], B, To, e, sk));
           }
           if (d < nd - 1) {
-            act_t* xn = (d & 1) ? xB : xA;
+            act_t* xn = xAB[k][d & 1];
             Epi e; e.flags = EPI_RESID | EPI_LRELU2; e.R = x; e.act_slope = slope; e.C2 = xa[idx(s, k, d + 1)];
-            RUN(conv_fwd_1d(c2[id], ha[id], xn, B, To, e, st));
+            RUN(conv_fwd_1d(c2[id], ha[id], xn, B, To, e, sk));
             x = xn;
           } else {
             Epi e; e.flags = EPI_RESID; e.R = x; e.alpha = 1.f / nk;
             if (k > 0) e.flags |= EPI_ACCUM;
             if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
-            RUN(conv_fwd_1d(c2[id], ha[id], sum, B, To, e, st));
+            if (mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order
+            RUN(conv_fwd_1d(c2[id], ha[id], sum, B, To, e, sk));
+            if (mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
           }
         }
       }
+      if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);               // join
       arena.release(mk);
       cur_act = act_out[s];
       Tin = To;
@@ -163,28 +191,43 @@ struct HifiGan : Model {
       const int To = Ts[s], Tin = s == 0 ? T : Ts[s - 1], C = ups[s].Cop;
       const size_t n = (size_t)B * To * C;
       act_t* gxs = arena.bf(n);
-      act_t* gh = arena.bf(n);
-      act_t* gA = arena.bf(n);
-      act_t* gB = arena.bf(n);
+      act_t* ghk[DMX_MAX_STAGES];
+      act_t* gAB[DMX_MAX_STAGES][2];
+      for (int k = 0; k < nk; ++k) { ghk[k] = arena.bf(n); gAB[k][0] = arena.bf(n); gAB[k][1] = arena.bf(n); }
       const int Cin = ups[s].Cip;
       act_t* gprev = arena.bf((size_t)B * Tin * Cin);
       CHECK_WS("hifigan");
+      const bool mt = multi();
+      hipEvent_t fin_prev = nullptr;
+      if (mt) {
+        hipEvent_t e0 = next_event();
+        (void)hipEventRecord(e0, st);
+        for (int k = 1; k < nk; ++k) (void)hipStreamWaitEvent(bstream[k], e0, 0);
+      }
       for (int k = 0; k < nk; ++k) {
+        hipStream_t sk = (mt && k > 0) ? bstream[k] : st;
         const act_t* gc = g;
         for (int d = nd - 1; d >= 0; --d) {
           const int id = idx(s, k, d);
           {
             Epi e; e.flags = EPI_MASK; e.X = ha[id]; e.mask_slope = slope;
-            RUN(conv_bwd_1d(c2[id], gc, gh, B, To, e, st));
+            RUN(conv_bwd_1d(c2[id], gc, ghk[k], B, To, e, sk));
           }
           Epi e; e.flags = EPI_MASK | EPI_RESID; e.X = xa[id]; e.mask_slope = slope; e.R = gc;
           act_t* dst;
-          if (d == 0) { dst = gxs; if (k > 0) e.flags |= EPI_ACCUM; }
-          else dst = (gc == gA) ? gB : gA;
-          RUN(conv_bwd_1d(c1[id], gh, dst, B, To, e, st));
+          if (d == 0) {
+            dst = gxs;
+            if (k > 0) e.flags |= EPI_ACCUM;
+            if (mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);
+          } else {
+            dst = (gc == gAB[k][0]) ? gAB[k][1] : gAB[k][0];
+          }
+          RUN(conv_bwd_1d(c1[id], ghk[k], dst, B, To, e, sk));
+          if (d == 0 && mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
           gc = dst;
         }
       }
+      if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);
       // through the upsampler (strided conv) and the leaky-relu that fed it
       {
         Epi e; e.flags = EPI_MASK; e.mask_slope = slope;
