@@ -138,17 +138,18 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
   if ((Nk & 3) || (dh & 7)) { dmx_set_error("attention needs Nk %% 4 == 0 and head_dim %% 8 == 0 (Nk=%d, dh=%d)", Nk, dh); return DMX_ERR_SHAPE; }
   const float scale = 1.0f / sqrtf((float)dh);
   const size_t mk = A.mark();
-  float* S = A.f32((size_t)Z * Nq * Nk);
+  // scores are written by the GEMM epilogue as fp16 straight into the P buffer (row pitch Nkp) and soft-maxed in place:
+  // half the HBM traffic of an fp32 score matrix (the N = 1000 U-Net levels are write-bound on it)
   act_t* Pm = P_keep ? P_keep : A.bf((size_t)Z * Nq * Nkp);
   act_t* vT = A.bf((size_t)Z * dh * Nkp);
   GemmBatch gb;
   gb.Z = Z; gb.Zi = heads;
   gb.sAo = (long long)Nq * C; gb.sAi = dh;
   gb.sBo = (long long)Nk * C; gb.sBi = dh;
-  gb.sCo = (long long)heads * Nq * Nk; gb.sCi = (long long)Nq * Nk;
-  Epi e; e.flags = EPI_F32OUT; e.alpha = scale;
-  CRUN(gemm_nt(q, C, k, C, S, Nk, Nq, Nk, dh, e, gb, cx.st));
-  CRUN(dmx_softmax_fwd(S, Pm, colbias, (long long)Z * Nq, Nk, Nk, Nkp, heads * Nq, cx.st));
+  gb.sCo = (long long)heads * Nq * Nkp; gb.sCi = (long long)Nq * Nkp;
+  Epi e; e.alpha = scale;
+  CRUN(gemm_nt(q, C, k, C, Pm, Nkp, Nq, Nk, dh, e, gb, cx.st));
+  CRUN(dmx_softmax_act(Pm, Pm, colbias, (long long)Z * Nq, Nk, Nkp, heads * Nq, cx.st));
   if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
   // vT[z] (dh, Nkp) = v[b, :, h*dh:(h+1)*dh]^T
   CRUN(dmx_transpose(v, vT, Nk, dh, C, Nkp, Z, heads, (long long)Nk * C, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));

@@ -293,6 +293,47 @@ __global__ __launch_bounds__(256) void softmax_kernel(const float* __restrict__ 
   }
 }
 
+// fp16-score variant (in place allowed): S and P share the (rows, ldp) fp16 buffer written by the score GEMM.
+template <int TPR>
+__global__ __launch_bounds__(256) void softmax_act_kernel(const act_t* __restrict__ S, act_t* __restrict__ P, const float* __restrict__ colbias,
+                                                          long long rows, int N, long long ldp, int rows_per_bias) {
+  __shared__ float sh[16];
+  constexpr int RPB = 256 / TPR;
+  const long long row = (long long)blockIdx.x * RPB + threadIdx.x / TPR;
+  const int t = threadIdx.x % TPR;
+  const bool live = row < rows;
+  const act_t* s = S + (live ? row : 0) * ldp;
+  const float* cb = colbias ? colbias + ((live ? row : 0) / rows_per_bias) * N : nullptr;
+  float v[16];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = (q * TPR + t) * 4;
+    float x0 = -3.0e38f, x1 = -3.0e38f, x2 = -3.0e38f, x3 = -3.0e38f;
+    if (live && c < N) {
+      const uint2 u = *reinterpret_cast<const uint2*>(s + c);
+      x0 = alo(u.x); x1 = ahi(u.x); x2 = alo(u.y); x3 = ahi(u.y);
+      if (cb) { const float4 bb = *reinterpret_cast<const float4*>(cb + c); x0 += bb.x; x1 += bb.y; x2 += bb.z; x3 += bb.w; }
+    }
+    v[q * 4] = x0; v[q * 4 + 1] = x1; v[q * 4 + 2] = x2; v[q * 4 + 3] = x3;
+    mx = fmaxf(mx, fmaxf(fmaxf(x0, x1), fmaxf(x2, x3)));
+  }
+  if (TPR == 64) mx = wave_max(mx); else mx = block_max(mx, sh);
+  float sum = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { v[q] = __expf(v[q] - mx); sum += v[q]; }
+  if (TPR == 64) sum = wave_sum(sum); else sum = block_sum(sum, sh);
+  const float inv = 1.f / sum;
+  if (!live) return;
+  act_t* p = P + row * ldp;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = (q * TPR + t) * 4;
+    if (c < N) *reinterpret_cast<uint2*>(p + c) = make_uint2(pack2a(v[q * 4] * inv, v[q * 4 + 1] * inv), pack2a(v[q * 4 + 2] * inv, v[q * 4 + 3] * inv));
+    else if (c < ldp) *reinterpret_cast<uint2*>(p + c) = make_uint2(0u, 0u);
+  }
+}
+
 // dS = P * (dP - sum_j dP_j P_j) * scale ; P bf16, dP fp32 -> dS bf16
 __global__ void softmax_bwd_kernel(const act_t* __restrict__ P, const float* __restrict__ dP, act_t* __restrict__ dS,
                                    int N, long long ld, float scale) {
@@ -559,6 +600,16 @@ int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long ro
     hipLaunchKernelGGL(softmax_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, colbias, rows, N, lds, ldp, rpb);
   else
     hipLaunchKernelGGL(softmax_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, S, P, colbias, rows, N, lds, ldp, rpb);
+  return CHECK_LAUNCH();
+}
+int dmx_softmax_act(const act_t* S, act_t* P, const float* colbias, long long rows, int N, long long ldp, int rows_per_bias,
+                    hipStream_t st) {
+  if ((N & 3) || (ldp & 3) || N > 4096) return DMX_ERR_SHAPE;
+  const int rpb = rows_per_bias < 1 ? 1 : rows_per_bias;
+  if (N <= 1024)
+    hipLaunchKernelGGL(softmax_act_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, colbias, rows, N, ldp, rpb);
+  else
+    hipLaunchKernelGGL(softmax_act_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, S, P, colbias, rows, N, ldp, rpb);
   return CHECK_LAUNCH();
 }
 int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,

@@ -15,6 +15,8 @@ int dmx_layernorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
                       hipStream_t st);
 int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long rows, int N, long long lds, long long ldp,
                     int rows_per_bias, hipStream_t st);
+int dmx_softmax_act(const act_t* S, act_t* P, const float* colbias, long long rows, int N, long long ldp, int rows_per_bias,
+                    hipStream_t st);
 int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,
                     hipStream_t st);
 int dmx_geglu(const act_t* x, act_t* y, long long rows, int I, hipStream_t st);
