@@ -87,7 +87,7 @@ enum {
   EPI_TANH = 64,       // v = tanh(v)
   EPI_F32OUT = 128,    // C is float* instead of bf16*
   EPI_NO_C = 256,      // skip the primary output (only C2)
-  EPI_GELU_GATE = 512  // unused
+  EPI_RESID_INV = 512  // R holds leaky_relu(x, 1/resid_inv_slope): the residual added is the reconstructed x
 };
 
 struct GemmDesc {
@@ -111,6 +111,7 @@ struct GemmDesc {
   float alpha, act_slope, mask_slope;
   int flags;
   signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
+  float resid_inv_slope;
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);

@@ -51,7 +51,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
       }
       if (flags & EPI_RESID) {
         const uint2 rr = *reinterpret_cast<const uint2*>(p.R + coff + orow * p.ldr + n);
-        v[0] += alo(rr.x); v[1] += ahi(rr.x); v[2] += alo(rr.y); v[3] += ahi(rr.y);
+        float r0 = alo(rr.x), r1 = ahi(rr.x), r2 = alo(rr.y), r3 = ahi(rr.y);
+        if (flags & EPI_RESID_INV) {
+          const float is = p.resid_inv_slope;
+          r0 = r0 > 0.f ? r0 : r0 * is; r1 = r1 > 0.f ? r1 : r1 * is; r2 = r2 > 0.f ? r2 : r2 * is; r3 = r3 > 0.f ? r3 : r3 * is;
+        }
+        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
       }
       const float al = p.alpha;
       v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
@@ -189,8 +194,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
           }
         }
     }
-    if (flags & EPI_RESID)
-      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+    if (flags & EPI_RESID) {
+      const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
+      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+        a[0] += x0 > 0.f ? x0 : x0 * is; a[1] += x1 > 0.f ? x1 : x1 * is; a[2] += x2 > 0.f ? x2 : x2 * is; a[3] += x3 > 0.f ? x3 : x3 * is;
+      });
+    }
     {
       const float al = p.alpha;
 #pragma unroll

@@ -114,13 +114,12 @@ struct HifiGan : Model {
           xa[idx(s, k, d)] = d == 0 ? xs_a[s] : arena.bf(n);
         }
       const size_t mk = arena.mark();       // transients below are released per stage
-      act_t* xs = arena.bf(n);
+      // the raw residual stream x is never stored: a conv reads the leaky-relu'd tensor it needs anyway, and the residual
+      // add reconstructs x = a > 0 ? a : a / slope in the epilogue (EPI_RESID_INV) -- one 16-bit tensor write less per conv2
       act_t* sum = arena.bf(n);
-      act_t* xAB[DMX_MAX_STAGES][2];
-      for (int k = 0; k < nk; ++k) { xAB[k][0] = arena.bf(n); xAB[k][1] = arena.bf(n); }
       {
-        Epi e; e.flags = EPI_LRELU2; e.act_slope = slope; e.C2 = xs_a[s];
-        RUN(conv_fwd_1d(up, cur_act, xs, B, Tin, e, st));
+        Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = xs_a[s];
+        RUN(conv_fwd_1d(up, cur_act, xs_a[s], B, Tin, e, st));
       }
       const float next_slope = (s == ns - 1) ? 0.01f : slope;
       const bool mt = multi();
@@ -132,7 +131,6 @@ struct HifiGan : Model {
       }
       for (int k = 0; k < nk; ++k) {
         hipStream_t sk = (mt && k > 0) ? bstream[k] : st;
-        const act_t* x = xs;
         for (int d = 0; d < nd; ++d) {
           const int id = idx(s, k, d);
           {
@@ -140,12 +138,12 @@ struct HifiGan : Model {
             RUN(conv_fwd_1d(c1[id], xa[id], ha[id], B, To, e, sk));
           }
           if (d < nd - 1) {
-            act_t* xn = xAB[k][d & 1];
-            Epi e; e.flags = EPI_RESID | EPI_LRELU2; e.R = x; e.act_slope = slope; e.C2 = xa[idx(s, k, d + 1)];
+            act_t* xn = xa[idx(s, k, d + 1)];
+            Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
+            e.act_slope = slope; e.C2 = xn;
             RUN(conv_fwd_1d(c2[id], ha[id], xn, B, To, e, sk));
-            x = xn;
           } else {
-            Epi e; e.flags = EPI_RESID; e.R = x; e.alpha = 1.f / nk;
+            Epi e; e.flags = EPI_RESID | EPI_RESID_INV; e.R = xa[id]; e.resid_inv_slope = 1.f / slope; e.alpha = 1.f / nk;
             if (k > 0) e.flags |= EPI_ACCUM;
             if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
             if (mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order

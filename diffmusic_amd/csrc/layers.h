@@ -69,7 +69,7 @@ struct ConvLayer {
 
 struct Epi {
   int flags = 0;
-  float alpha = 1.f, act_slope = 0.f, mask_slope = 0.f;
+  float alpha = 1.f, act_slope = 0.f, mask_slope = 0.f, resid_inv_slope = 1.f;
   const act_t* R = nullptr;
   const act_t* X = nullptr;
   act_t* C2 = nullptr;

@@ -155,7 +155,7 @@ static void init_desc(GemmDesc& d, const Epi& e) {
   memset(&d, 0, sizeof(d));
   d.Z = 1; d.Zi = 1;
   d.sy = d.sx = 1; d.osy = d.osx = 1;
-  d.alpha = e.alpha; d.act_slope = e.act_slope; d.mask_slope = e.mask_slope;
+  d.alpha = e.alpha; d.act_slope = e.act_slope; d.mask_slope = e.mask_slope; d.resid_inv_slope = e.resid_inv_slope;
   d.flags = e.flags;
   d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias;
 }
