@@ -157,7 +157,7 @@ def main():
     achieved = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": None,
-                "kernel": "gemm_kernel<128,*> (implicit-GEMM conv / batched NT GEMM, fp16 MFMA)",
+                "kernel": "gemm_glds_kernel<256,*> + gemm_kernel<128|64,*> (implicit-GEMM conv / batched NT GEMM family, fp16 MFMA)",
                 "launches_per_step": n_launch, "kernel_ms_per_step": round(ms.value, 3),
                 "issued_tflop_per_step": round(fl.value / 1e12, 2), "algorithmic_tflop_per_step": algo_tflop_step,
                 "step_share": round(ms.value / (1e3 * wall / args.steps), 3)}
