@@ -11,8 +11,21 @@
 // residual, resblock averaging, leaky-relu of the stored activation, leaky-relu' mask for dgrad,
 // tanh) is fused into the epilogue.
 #include "dmx_common.h"
+#include <type_traits>
 
 namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+#ifndef DMX_NO_SWP
+#define DMX_SWP 1   // hand-scheduled fragment pipeline in the LDS-DMA kernels (default on)
+#endif
 
 constexpr int BK = 64;  // bf16 elements per K-step (128 B per tile row)
 
@@ -497,6 +510,55 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
 #endif
     const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
     const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
+#ifdef DMX_SWP
+    {
+      // Hand-scheduled fragment pipeline.  hipcc sinks every ds_read next to its consumer (read 2, wait, 4-8 MFMAs: the LDS
+      // latency is exposed 16x per K-step and the matrix pipe idles ~50 %).  Here the reads are inline asm issued two steps
+      // (2*FN MFMAs) ahead of their use, with counted lgkmcnt waits computed at compile time from the issue order (LDS
+      // returns in order), and sched_barrier fences so the MFMAs of a step cannot be hoisted above its wait.
+      constexpr int NS = 2 * FM;                                   // steps per K-step: (kk, i), FN MFMAs each
+      constexpr int P0 = FN + 2;                                   // prologue reads: wf0[0..FN), af[0], af[1]
+      const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(sa);
+      const unsigned b0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(sb);
+      const unsigned sw0 = ((0 * 4 + lq) ^ (lr & 7)) << 4, sw1 = ((1 * 4 + lq) ^ (lr & 7)) << 4;
+      const unsigned aA0 = a0 + sw0, aA1 = a0 + sw1, aB0 = b0 + sw0, aB1 = b0 + sw1;
+      frag8_t wf0[FN], wf1[FN], af[NS];
+#define DMX_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+      static_for<0, FN>([&wf0, aB0](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf0[j], aB0, j * 2048); });
+      DMX_DSR(af[0], aA0, 0);
+      if constexpr (FM > 1) { DMX_DSR(af[1], aA0, 2048); } else { DMX_DSR(af[1], aA1, 0); }
+      static_for<0, NS>([&wf0, &wf1, &af, &acc, aA0, aA1, aB1](auto ST) {
+        constexpr int st = decltype(ST)::value;
+        constexpr bool pre_a = st + 2 < NS;
+        constexpr bool pre_w = st >= FM - FN && st < FM;
+        if constexpr (pre_a) {
+          constexpr int s2 = st + 2, k2 = s2 / FM, i2 = s2 - k2 * FM;
+          if constexpr (k2 == 0) { DMX_DSR(af[s2], aA0, i2 * 2048); } else { DMX_DSR(af[s2], aA1, i2 * 2048); }
+        }
+        if constexpr (pre_w) {                                      // weights of kk = 1 trickle in during the tail of kk = 0
+          constexpr int j = st - (FM - FN);
+          DMX_DSR(wf1[j], aB1, j * 2048);
+        }
+        // issue-order bookkeeping (all constexpr): reads issued through this step and the newest one this step depends on
+        constexpr auto r = [](int t) { return (t + 2 < NS ? 1 : 0) + ((t >= FM - FN && t < FM) ? 1 : 0); };
+        constexpr auto issued_through = [r](int t) { int n = P0; for (int q = 0; q <= t; ++q) n += r(q); return n; };
+        constexpr int total = issued_through(st);
+        constexpr int pos_af = st == 0 ? FN + 1 : (st == 1 ? FN + 2 : issued_through(st - 3 < 0 ? -1 : st - 3) + 1);
+        constexpr int pos_w = st < FM ? FN : issued_through(FM - 1);
+        constexpr int need = pos_af > pos_w ? pos_af : pos_w;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(total - need) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int kk = st / FM, i = st - kk * FM;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+#undef DMX_DSR
+#ifdef DMX_ISSUE_MID
+      issue(ks + NSTAGE - 1, nxt);
+#endif
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int sw = ((kk * 4 + lq) ^ (lr & 7)) << 4;
@@ -536,6 +598,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
       if (kk == 0) issue(ks + NSTAGE - 1, nxt);
 #endif
     }
+#endif
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
 #ifndef DMX_NOBARRIER
     __builtin_amdgcn_s_barrier();
