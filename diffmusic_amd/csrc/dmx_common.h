@@ -112,6 +112,7 @@ struct GemmDesc {
   int flags;
   signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
   float resid_inv_slope;
+  int tile_cfg;          // 0 = automatic; 1..6 force a tile configuration (tuning hook)
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);

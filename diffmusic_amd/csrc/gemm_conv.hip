@@ -664,12 +664,37 @@ namespace {
 struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, Z, taps, flags; };
 bool g_prof = false;
 std::vector<ProfRec> g_prof_recs;
+// tile configurations: 1 = LDS-DMA 256x256, 2 = LDS-DMA 256x128, 3 = 128x128, 4 = 128x64, 5 = 128x32, 6 = 64x64
+struct TileEntry { int M, N, K, Z, cfg; };
+static const TileEntry g_tile_table[] = {
+#ifndef DMX_NO_TILE_TABLE
+#include "tile_table.inc"
+#endif
+    {0, 0, 0, 0, 0}};
+
+bool glds_ok(const GemmDesc& d) {
+  // operand spans must stay below 2 GiB for the 32-bit buffer offsets of the LDS-DMA kernels
+  return (long long)d.M * d.lda < (1ll << 29) && (long long)d.N * d.ldw < (1ll << 29) && d.sy == 1;
+}
+int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
+  switch (cfg) {
+    case 1: return launch_glds<256, 256, 2, 4, 2>(d, stream);
+    case 2: return launch_glds<256, 128, 4, 2, 3>(d, stream);
+    case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
+    case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
+    case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
+    default: return launch_cfg<64, 64, 2, 2>(d, stream);
+  }
+}
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
-  // operand spans must stay below 2 GiB for the 32-bit buffer offsets of the LDS-DMA kernels
-  const bool span_ok = (long long)d.M * d.lda < (1ll << 29) && (long long)d.N * d.ldw < (1ll << 29) && d.sy == 1 && d.Z >= 1;
-  if (!legacy && span_ok && d.M >= 2048 && d.N % 128 == 0) {
-    // pick the tile that minimises (rounds over the 256 CUs) x (time per block); efficiencies measured on MI355X
+  const bool gl = !legacy && glds_ok(d);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 6 && (d.tile_cfg > 2 || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  // measured best configuration for the shapes of the shipped benchmark configs (scripts/dev/tune_tiles.py)
+  for (const TileEntry* e = g_tile_table; e->cfg; ++e)
+    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && (e->cfg > 2 || gl)) return launch_by_cfg(e->cfg, d, stream);
+  if (gl && d.M >= 2048 && d.N % 128 == 0) {
+    // otherwise pick the tile that minimises (rounds over the 256 CUs) x (time per block); efficiencies measured on MI355X
     auto cost = [&](int bm, int bn, int slots, double eff) {
       const double blocks = (double)cdiv(d.M, bm) * cdiv(d.N, bn) * d.Z;
       const double rounds = ceil(blocks / slots);
@@ -678,14 +703,14 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     const double cA = d.N % 256 == 0 ? cost(256, 256, 256, 0.95) : 1e30;
     const double cB = cost(256, 128, 256, 0.70);
     const double cC = cost(128, 128, 512, 0.66);
-    if (cA <= cB && cA <= cC) return launch_glds<256, 256, 2, 4, 2>(d, stream);
-    if (cB <= cC) return launch_glds<256, 128, 4, 2, 3>(d, stream);
+    if (cA <= cB && cA <= cC) return launch_by_cfg(1, d, stream);
+    if (cB <= cC) return launch_by_cfg(2, d, stream);
   }
   // small problems: 64x64 tiles so that at least ~1 block per CU exists (U-Net levels with 1k-4k pixels)
-  if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) return launch_cfg<64, 64, 2, 2>(d, stream);
-  if (d.N > 64) return launch_cfg<128, 128, 2, 2>(d, stream);
-  if (d.N > 32) return launch_cfg<128, 64, 2, 2>(d, stream);
-  return launch_cfg<128, 32, 4, 1>(d, stream);
+  if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) return launch_by_cfg(6, d, stream);
+  if (d.N > 64) return launch_by_cfg(3, d, stream);
+  if (d.N > 32) return launch_by_cfg(4, d, stream);
+  return launch_by_cfg(5, d, stream);
 }
 }  // namespace
 
