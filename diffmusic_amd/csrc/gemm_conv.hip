@@ -100,6 +100,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
+// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM)
+template <int FM>
+struct EpiChunk { static constexpr int IB = (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 3 : (FM % 2 == 0) ? 2 : 1; static constexpr int CH = IB * 16; };
+
 // ---------------------------------------------------------------------------------------------
 // LDS-staged epilogue for fp16 outputs.  The MFMA accumulator layout gives a lane 4 channels of one pixel
 // (8-byte pieces, 32-byte runs per row); written straight to HBM that is 1/4 of a cache line per row and the
@@ -110,9 +114,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
                                                   long long coff, int HqWq, char* wl) {
-  constexpr int TM = FM * 16;
-  constexpr int CH = TM < 64 ? TM : 64;
-  constexpr int IB = CH / 16;
+  constexpr int CH = EpiChunk<FM>::CH;
+  constexpr int IB = EpiChunk<FM>::IB;
   constexpr int TNB = FN * 32;            // bytes per tile row
   constexpr int PITCH = TNB + 16;
   constexpr int CPR = TNB / 16;           // 16-byte chunks per row
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
-    constexpr int EPI_CH = (FM * 16 < 64 ? FM * 16 : 64);
+    constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
     gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
@@ -530,17 +533,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
       static_for<0, NS>([&wf0, &wf1, &af, &acc, aA0, aA1, aB1](auto ST) {
         constexpr int st = decltype(ST)::value;
         constexpr bool pre_a = st + 2 < NS;
-        constexpr bool pre_w = st >= FM - FN && st < FM;
+        // weights of kk = 1 trickle in during kk = 0: step st (< FM) fetches wf1[j] for j in [st*FN/FM, (st+1)*FN/FM)
+        constexpr int w_lo = st < FM ? st * FN / FM : 0, w_hi = st < FM ? (st + 1) * FN / FM : 0;
         if constexpr (pre_a) {
           constexpr int s2 = st + 2, k2 = s2 / FM, i2 = s2 - k2 * FM;
           if constexpr (k2 == 0) { DMX_DSR(af[s2], aA0, i2 * 2048); } else { DMX_DSR(af[s2], aA1, i2 * 2048); }
         }
-        if constexpr (pre_w) {                                      // weights of kk = 1 trickle in during the tail of kk = 0
-          constexpr int j = st - (FM - FN);
-          DMX_DSR(wf1[j], aB1, j * 2048);
-        }
+        static_for<w_lo, w_hi>([&wf1, aB1](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf1[j], aB1, j * 2048); });
         // issue-order bookkeeping (all constexpr): reads issued through this step and the newest one this step depends on
-        constexpr auto r = [](int t) { return (t + 2 < NS ? 1 : 0) + ((t >= FM - FN && t < FM) ? 1 : 0); };
+        constexpr auto r = [](int t) { return (t + 2 < NS ? 1 : 0) + (t < FM ? (t + 1) * FN / FM - t * FN / FM : 0); };
         constexpr auto issued_through = [r](int t) { int n = P0; for (int q = 0; q <= t; ++q) n += r(q); return n; };
         constexpr int total = issued_through(st);
         constexpr int pos_af = st == 0 ? FN + 1 : (st == 1 ? FN + 2 : issued_through(st - 3 < 0 ? -1 : st - 3) + 1);
@@ -614,7 +615,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
-    constexpr int EPI_CH = (FM * 16 < 64 ? FM * 16 : 64);
+    constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
     gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
@@ -680,6 +681,10 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   switch (cfg) {
     case 1: return launch_glds<256, 256, 2, 4, 2>(d, stream);
     case 2: return launch_glds<256, 128, 4, 2, 3>(d, stream);
+    case 7: return launch_glds<320, 256, 2, 4, 2>(d, stream);
+    case 8: return launch_glds<192, 256, 2, 4, 2>(d, stream);
+    case 9: return launch_glds<320, 128, 4, 2, 2>(d, stream);
+    case 10: return launch_glds<192, 128, 4, 2, 3>(d, stream);
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -689,10 +694,10 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 6 && (d.tile_cfg > 2 || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 10 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   // measured best configuration for the shapes of the shipped benchmark configs (scripts/dev/tune_tiles.py)
   for (const TileEntry* e = g_tile_table; e->cfg; ++e)
-    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && (e->cfg > 2 || gl)) return launch_by_cfg(e->cfg, d, stream);
+    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && ((e->cfg > 2 && e->cfg < 7) || gl)) return launch_by_cfg(e->cfg, d, stream);
   if (gl && d.M >= 2048 && d.N % 128 == 0) {
     // otherwise pick the tile that minimises (rounds over the 256 CUs) x (time per block); efficiencies measured on MI355X
     auto cost = [&](int bm, int bn, int slots, double eff) {
@@ -700,11 +705,23 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
       const double rounds = ceil(blocks / slots);
       return rounds * (bm / 128.0) * (bn / 128.0) * (slots / 256.0) / eff;
     };
-    const double cA = d.N % 256 == 0 ? cost(256, 256, 256, 0.95) : 1e30;
-    const double cB = cost(256, 128, 256, 0.70);
-    const double cC = cost(128, 128, 512, 0.66);
-    if (cA <= cB && cA <= cC) return launch_by_cfg(1, d, stream);
-    if (cB <= cC) return launch_by_cfg(2, d, stream);
+    // candidates: LDS-DMA tiles with 192 / 256 / 320 rows (the row count is chosen to fill whole rounds of 256 CUs:
+    // M = 40 008 x N = 512 is 314 tiles of 256x256 = 2 rounds at 61 %, but 252 tiles of 320x256 = 1 round at 98 %)
+    struct Cand { int cfg, bm, bn, slots; double eff; };
+    static const Cand cands[] = {{1, 256, 256, 256, 0.95}, {7, 320, 256, 256, 0.93}, {8, 192, 256, 256, 0.88},
+                                 {2, 256, 128, 256, 0.70}, {9, 320, 128, 256, 0.70}, {10, 192, 128, 256, 0.66},
+                                 {3, 128, 128, 512, 0.66}};
+    int best = 0;
+    double bc = 1e30;
+    for (const Cand& c : cands) {
+      if (c.bn == 256 && d.N % 256) continue;
+#ifdef DMX_NO_EXTRA_TILES
+      if (c.cfg >= 7) continue;
+#endif
+      const double v = cost(c.bm, c.bn, c.slots, c.eff);
+      if (v < bc) { bc = v; best = c.cfg; }
+    }
+    if (best && best != 3) return launch_by_cfg(best, d, stream);
   }
   // small problems: 64x64 tiles so that at least ~1 block per CU exists (U-Net levels with 1k-4k pixels)
   if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) return launch_by_cfg(6, d, stream);

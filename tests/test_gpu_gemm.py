@@ -102,3 +102,22 @@ def test_batched_nt_gemm_f32_out_and_mask():
     _run(L, d)
     ref = (a.float() @ b.float().transpose(1, 2)) * torch.where(xm.float() > 0, 1.0, 0.1)
     assert _rel(outb, ref) < 6e-3
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10])
+def test_forced_tile_configs_agree(cfg):
+    """every tile configuration (incl. the 320x256 LDS-DMA tile) gives the same conv result"""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    B, T, Ci, Co, k, dil = 2, 2400, 128, 256, 7, 3
+    x = torch.randn(B, T, Ci, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Co, Ci, k, generator=g) / (Ci * k) ** 0.5).to(_adt()).cuda()
+    res = torch.randn(B, T, Co, generator=g).to(_adt()).cuda()
+    pad = (k * dil - dil) // 2
+    wp = w.permute(0, 2, 1).reshape(Co, k * Ci).contiguous()
+    out = torch.empty(B, T, Co, dtype=_adt(), device="cuda")
+    d = _desc(L, A=x, W=wp, C=out, R=res, M=B * T, N=Co, K=k * Ci, ldw=k * Ci, Hi=1, Wi=T, Ci=Ci, lda=Ci, Hq=1, Wq=T, ntaps=k, Ho=1, Wo=T,
+              ldc=Co, ldr=Co, ldx=Co, ldc2=Co, flags=L.EPI_RESID, tdy=[0] * k, tdx=[t * dil - pad for t in range(k)], tile_cfg=cfg)
+    _run(L, d)
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), None, padding=pad, dilation=dil).transpose(1, 2) + res.float()
+    assert _rel(out, ref) < 3e-3
