@@ -42,29 +42,56 @@ def synth_clip(k, length):
     return (y + 0.01 * torch.randn(length, generator=g)).clamp(-1, 1)
 
 
-def build_problem(B, rank, device):
+WORKLOADS = {
+    # name: (pipeline, scheduler, eta, rate, task, clips per GPU, BASELINE.json config)
+    "dps_inpainting": ("musicldm", "dps", 0.0, 5e-4, "music_inpainting", 8, "configs[1]"),
+    "dsg_phase_audioldm2": ("audioldm2", "dsg", 1.0, 0.08, "phase_retrieval", 4, "configs[2] (4 clips per GPU)"),
+    "mpgd_sr4": ("musicldm", "mpgd", 0.0, 5e-3, "super_resolution", 4, "configs[3] (4 clips per GPU)"),
+}
+
+
+def build_problem(B, rank, device, workload="dps_inpainting"):
     from diffmusic_amd.pipelines import get_pipeline
     from diffmusic_amd.schedulers import get_scheduler
-    from diffmusic_amd.inverse_problem import MusicInpaintingOperator, get_noiser
+    from diffmusic_amd import inverse_problem as P
     from diffmusic_amd.torch_utils import randn_tensor
-    pipe = get_pipeline("musicldm").from_pretrained("synthetic", seed=0).to(device)
-    op = MusicInpaintingOperator(SECONDS, SR, "box", 2, 3, 0.3, 0.1, 1.0, noiser=get_noiser("gaussian", 0.0))
-    pipe.scheduler = get_scheduler("dps")(operator=op, **SCHED_CFG)
+    pname, sname, eta, rate, task, _, _ = WORKLOADS[workload]
+    pipe = get_pipeline(pname).from_pretrained("synthetic", seed=0).to(device)
+    noiser = P.get_noiser("gaussian", 0.0)
+    if task == "music_inpainting":
+        op = P.MusicInpaintingOperator(SECONDS, SR, "box", 2, 3, 0.3, 0.1, 1.0, noiser=noiser)
+    elif task == "phase_retrieval":
+        op = P.PhaseRetrievalOperator(noiser=noiser)
+    else:
+        op = P.SuperResolutionOperator(SR, 4, noiser=noiser)
+    pipe.scheduler = get_scheduler(sname)(operator=op, **SCHED_CFG)
     pipe.scheduler.set_timesteps(N_STEPS, device=device)
     L = SECONDS * SR
     clips = torch.stack([synth_clip(rank * B + i, L) for i in range(B)]).to(device)
     measurement = op.forward(clips)
     gens = [torch.Generator().manual_seed(rank * B + i) for i in range(B)]
     latents = randn_tensor((B, 8, 250, 16), generator=gens, device=device, dtype=torch.float32)
-    pe = torch.nn.functional.normalize(torch.randn(B, 512, generator=torch.Generator().manual_seed(7)), dim=-1).to(device)
-    pe2 = torch.cat([pe, pe], dim=0)          # prompt="" in the reference: cond == uncond, CFG batch kept at 2B
-    return pipe, op, measurement, latents, pe2, L
+    g7 = torch.Generator().manual_seed(7)
+    if pname == "musicldm":
+        pe = torch.nn.functional.normalize(torch.randn(B, 512, generator=g7), dim=-1).to(device)
+        cond = dict(class_labels=torch.cat([pe, pe], dim=0))      # prompt="" in the reference: cond == uncond, CFG batch kept at 2B
+        gscale = GUIDANCE_SCALE
+    else:                                                          # AudioLDM2: GPT-2 states (B,8,768), T5 states (B,16,1024), mask ones
+        ge = torch.randn(B, 8, 768, generator=g7).to(device)
+        te = torch.randn(B, 16, 1024, generator=g7).to(device)
+        cond = dict(class_labels=None, encoder_hidden_states=torch.cat([ge, ge]), encoder_hidden_states_1=torch.cat([te, te]),
+                    encoder_attention_mask_1=torch.ones(2 * B, 16, device=device))
+        gscale = 3.5
+    pipe._bench = dict(eta=eta, rate=rate, gscale=gscale, gens=gens)
+    return pipe, op, measurement, latents, cond, L
 
 
-def one_step(pipe, latents, t, pe2, measurement, L):
-    eps = pipe._unet_eps(latents, t, pe2, GUIDANCE_SCALE, True)
-    out = pipe.scheduler.step(eps, t, latents, eta=0.0, measurement=measurement, vae=pipe.vae, vocoder=pipe.vocoder,
-                              original_waveform_length=L, ip_guidance_rate=ZETA, supervised_space="mel_spectrogram")
+def one_step(pipe, latents, t, cond, measurement, L):
+    b = pipe._bench
+    eps = pipe._unet_eps(latents, t, cond, b["gscale"], True)
+    out = pipe.scheduler.step(eps, t, latents, eta=b["eta"], generator=b["gens"], measurement=measurement, vae=pipe.vae,
+                              vocoder=pipe.vocoder, original_waveform_length=L, ip_guidance_rate=b["rate"],
+                              supervised_space="mel_spectrogram")
     return out.prev_sample, out.loss
 
 
@@ -103,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="dps_inpainting", choices=sorted(WORKLOADS),
+                    help="default = the headline config (BASELINE.json configs[1]); the others are the remaining GPU configs")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -113,8 +142,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    B = args.batch
-    pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device)
+    wl = args.workload
+    B = args.batch if wl == "dps_inpainting" else WORKLOADS[wl][5]
+    pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device, wl)
     ts = pipe.scheduler._timesteps_host
 
     def barrier():
@@ -153,7 +183,8 @@ def main():
     one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
     ms, fl = C.c_double(), C.c_double()
     n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
-    algo_tflop_step = ALGO_TFLOP_PER_CLIP_STEP * B
+    # headline config: the analytic count of BASELINE.md; other workloads: the FLOPs the launches actually issued
+    algo_tflop_step = ALGO_TFLOP_PER_CLIP_STEP * B if wl == "dps_inpainting" else fl.value / 1e12
     achieved = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": None,
@@ -165,16 +196,18 @@ def main():
     if rank == 0:
         steps_per_s = args.steps / wall * world                 # one step advances B clips on each of `world` GPUs
         res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4),
-               "unit": "steps/s (each step advances a batch of 8 clips)", "n_gpus": world, "steps": args.steps,
+               "unit": f"steps/s (each step advances a batch of {B} clips per GPU)", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU "
-                                      "(BASELINE.json configs[1])", "global_batch": B * world, "clips_per_gpu": B,
+               "config": {"workload": {"dps_inpainting": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU "
+                                      "(BASELINE.json configs[1])"}.get(wl, f"{wl}: {WORKLOADS[wl][0]} + {WORKLOADS[wl][1]} {WORKLOADS[wl][4]}, 10 s @16 kHz, "
+                                                                        f"200-step schedule, {WORKLOADS[wl][6]}"),
+                          "global_batch": B * world, "clips_per_gpu": B,
                           "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world}",
                           "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite,
                           "final_loss_clip0": float(loss.reshape(-1)[0])},
                "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting":
             threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share, not the host's core count
             sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
             print(f"[bench] timing the CPU oracle on {threads} threads (1 clip x 4 steps) ...", file=sys.stderr, flush=True)
