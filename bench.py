@@ -185,12 +185,21 @@ def main():
     n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
     # headline config: the analytic count of BASELINE.md; other workloads: the FLOPs the launches actually issued
     algo_tflop_step = ALGO_TFLOP_PER_CLIP_STEP * B if wl == "dps_inpainting" else fl.value / 1e12
-    achieved = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
+    dms, dfl = C.c_double(), C.c_double()
+    n_dom = Lb.lib().dmx_prof_dominant(C.byref(dms), C.byref(dfl))
+    # dominant kernel = gemm_glds_kernel (LDS-DMA tiles): its issued FLOPs scaled by algorithmic/issued of the step
+    scale = algo_tflop_step / (fl.value / 1e12) if fl.value > 0 else 1.0
+    dom_tflop = dfl.value / 1e12 * scale
+    achieved = dom_tflop / (dms.value * 1e-3) if dms.value > 0 else 0.0
+    all_rate = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": None,
-                "kernel": "gemm_glds_kernel<256,*> + gemm_kernel<128|64,*> (implicit-GEMM conv / batched NT GEMM family, fp16 MFMA)",
-                "launches_per_step": n_launch, "kernel_ms_per_step": round(ms.value, 3),
-                "issued_tflop_per_step": round(fl.value / 1e12, 2), "algorithmic_tflop_per_step": algo_tflop_step,
+                "kernel": "gemm_glds_kernel (implicit-GEMM conv / batched NT GEMM on LDS-DMA tiles, fp16 MFMA)",
+                "launches_per_step": n_dom, "kernel_ms_per_step": round(dms.value, 3), "avg_launch_us": round(1e3 * dms.value / max(n_dom, 1), 1),
+                "algorithmic_tflop_per_step": round(dom_tflop, 2),
+                "all_gemm_kernels": {"launches_per_step": n_launch, "kernel_ms_per_step": round(ms.value, 3),
+                                     "algorithmic_tflop_per_step": round(algo_tflop_step, 2), "issued_tflop_per_step": round(fl.value / 1e12, 2),
+                                     "achieved": round(all_rate, 1), "frac": round(all_rate / PEAK_TFLOPS_16BIT, 4)},
                 "step_share": round(ms.value / (1e3 * wall / args.steps), 3)}
 
     if rank == 0:

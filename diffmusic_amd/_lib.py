@@ -86,6 +86,7 @@ _SIGS = {
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_destroy": (None, [C.c_void_p]),
     "dmx_audio_num_frames": (C.c_int, [C.c_void_p, C.c_int]),

@@ -662,7 +662,8 @@ int launch_cfg(const GemmDesc& d, hipStream_t stream) {
 #include <cstdlib>
 #include <cmath>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, Z, taps, flags; };
+struct ProfRec { hipEvent_t a, b; double flops; int M, N, K, Z, taps, flags, cfg; };
+int g_last_cfg = 0;   // tile configuration chosen by the most recent dispatch (profiling only)
 bool g_prof = false;
 std::vector<ProfRec> g_prof_recs;
 // tile configurations: 1 = LDS-DMA 256x256, 2 = LDS-DMA 256x128, 3 = 128x128, 4 = 128x64, 5 = 128x32, 6 = 64x64
@@ -678,6 +679,7 @@ bool glds_ok(const GemmDesc& d) {
   return (long long)d.M * d.lda < (1ll << 29) && (long long)d.N * d.ldw < (1ll << 29) && d.sy == 1;
 }
 int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
+  g_last_cfg = cfg;
   switch (cfg) {
     case 1: return launch_glds<256, 256, 2, 4, 2>(d, stream);
     case 2: return launch_glds<256, 128, 4, 2, 3>(d, stream);
@@ -739,16 +741,27 @@ extern "C" void dmx_prof_begin(void) {
   g_prof = true;
 }
 // stops recording; returns the number of launches, total kernel milliseconds and algorithmic FLOPs (2*M*N*K*Z)
+static double g_dma_ms = 0.0, g_dma_fl = 0.0;
+static int g_dma_n = 0;
+// share of the last profiled region that ran in gemm_glds_kernel (the dominant, MFMA-bound kernel)
+extern "C" int dmx_prof_dominant(double* ms, double* flops) {
+  if (ms) *ms = g_dma_ms;
+  if (flops) *flops = g_dma_fl;
+  return g_dma_n;
+}
 extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
   g_prof = false;
+  g_dma_ms = g_dma_fl = 0.0; g_dma_n = 0;
   (void)hipDeviceSynchronize();
   double ms = 0.0, fl = 0.0;
   FILE* csv = getenv("DMX_PROF_CSV") ? fopen(getenv("DMX_PROF_CSV"), "w") : nullptr;
-  if (csv) fprintf(csv, "M,N,K,Z,taps,flags,ms,tflops\n");
+  if (csv) fprintf(csv, "M,N,K,Z,taps,flags,cfg,ms,tflops\n");
   for (auto& r : g_prof_recs) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
-    if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, t, t > 0 ? r.flops / t / 1e9 : 0.0);
+    if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
+    const bool dma = r.cfg == 1 || r.cfg == 2 || r.cfg >= 7;          // gemm_glds_kernel (LDS-DMA tiles)
+    if (dma) { g_dma_ms += t; g_dma_fl += r.flops; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
@@ -773,6 +786,7 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   (void)hipEventRecord(r.a, stream);
   const int rc = launch_dispatch(d, stream);
   (void)hipEventRecord(r.b, stream);
+  r.cfg = g_last_cfg;
   g_prof_recs.push_back(r);
   return rc;
 }

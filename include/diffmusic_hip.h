@@ -178,6 +178,8 @@ int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, 
 /* ---- measurement hooks: HIP events around every implicit-GEMM launch (bench.py roofline leg) ---------- */
 void dmx_prof_begin(void);
 int dmx_prof_end(double* total_ms, double* total_flops); /* returns the number of launches recorded */
+/* of the region closed by the last dmx_prof_end: launches / kernel ms / FLOPs of gemm_glds_kernel (LDS-DMA tiles) alone */
+int dmx_prof_dominant(double* ms, double* flops);
 
 /* ---- low-level test hook: one implicit-GEMM launch described by the internal descriptor --------*/
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
