@@ -123,6 +123,24 @@ def cpu_baseline(seed_sd, threads):
     return (time.perf_counter() - t0) / n_meas
 
 
+def pmc_traffic(prefix):
+    """HBM-side bytes per launch of one kernel family from the committed counter passes
+    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate `rocprofv3 --pmc` runs of this same command,
+    KiB -> bytes, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be read from inside the process."""
+    import csv
+    tot, n = 0.0, 0
+    here = os.path.dirname(os.path.abspath(__file__))
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            with open(os.path.join(here, "profiles", f"r01_pmc_{c}_per_kernel.csv")) as fh:
+                rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(prefix)]
+            tot += sum(float(r[f"{c}_bytes_total"]) for r in rows)
+            n = sum(int(r["launches"]) for r in rows)
+    except (OSError, KeyError):
+        return None, None
+    return (round(tot / n) if n else None), "profiles/r01_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv (rocprofv3 --pmc, separate passes)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,15 +203,17 @@ def main():
     n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
     # headline config: the analytic count of BASELINE.md; other workloads: the FLOPs the launches actually issued
     algo_tflop_step = ALGO_TFLOP_PER_CLIP_STEP * B if wl == "dps_inpainting" else fl.value / 1e12
-    dms, dfl = C.c_double(), C.c_double()
-    n_dom = Lb.lib().dmx_prof_dominant(C.byref(dms), C.byref(dfl))
+    dms, dfl, dby = C.c_double(), C.c_double(), C.c_double()
+    n_dom = Lb.lib().dmx_prof_dominant(C.byref(dms), C.byref(dfl), C.byref(dby))
+    traffic, traffic_src = pmc_traffic("gemm_glds_kernel") if args.workload == "dps_inpainting" else (None, None)
     # dominant kernel = gemm_glds_kernel (LDS-DMA tiles): its issued FLOPs scaled by algorithmic/issued of the step
     scale = algo_tflop_step / (fl.value / 1e12) if fl.value > 0 else 1.0
     dom_tflop = dfl.value / 1e12 * scale
     achieved = dom_tflop / (dms.value * 1e-3) if dms.value > 0 else 0.0
     all_rate = algo_tflop_step / (ms.value * 1e-3) if ms.value > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_TFLOPS_16BIT, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": None,
+                "frac": round(achieved / PEAK_TFLOPS_16BIT, 4), "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(dby.value / max(n_dom, 1)),
                 "kernel": "gemm_glds_kernel (implicit-GEMM conv / batched NT GEMM on LDS-DMA tiles, fp16 MFMA)",
                 "launches_per_step": n_dom, "kernel_ms_per_step": round(dms.value, 3), "avg_launch_us": round(1e3 * dms.value / max(n_dom, 1), 1),
                 "algorithmic_tflop_per_step": round(dom_tflop, 2),

@@ -51,8 +51,8 @@ class GemmDesc(C.Structure):
                 ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int)]
 
 
-EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512
 
 _SIGS = {
     "dmx_abi_version": (C.c_int, []),
@@ -86,7 +86,8 @@ _SIGS = {
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dmx_conv_pair_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_destroy": (None, [C.c_void_p]),
     "dmx_audio_num_frames": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,4 +1,5 @@
 // extern "C" surface of libdiffmusic_hip.so (declared in include/diffmusic_hip.h).
+#include "conv_pair.h"
 #include "models.h"
 
 #define M_IMPL(m) ((m) ? (m)->impl : nullptr)
@@ -103,6 +104,14 @@ int dmx_unet_fwd_ctx(dmx_model* m, const float* x, const float* t, const float* 
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream) {
   if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
   return dmx_gemm_launch(*reinterpret_cast<const GemmDesc*>(desc), ST(stream));
+}
+
+int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes, void* stream) {
+  if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
+  const GemmDesc* a = reinterpret_cast<const GemmDesc*>(desc_a);
+  const GemmDesc& b = *reinterpret_cast<const GemmDesc*>(desc_b);
+  if (!dmx_conv_pair_eligible(a, b)) { dmx_set_error("shape not handled by the fused convolution-pair kernel"); return DMX_ERR_SHAPE; }
+  return dmx_conv_pair_launch(a, b, ST(stream));
 }
 
 }  // extern "C"

@@ -1,0 +1,373 @@
+// Fused pair of stride-1 dilated 1-D convolutions for the narrow (C = 32 / 64) HiFi-GAN resblock stages.
+//
+// A HiFi-GAN resblock step is conv1 -> leaky-relu -> conv2 -> (+ residual)  (transformers
+// modeling_speecht5.py HifiGanResidualBlock.forward; reached from the reference through
+// BaseOperator.inverse_transform, diffmusic/inverse_problem/operator.py:126-130), and its input-gradient
+// is dgrad(conv2) -> leaky-relu' -> dgrad(conv1) -> (+ residual).  At C <= 64 each convolution moves
+// 2.5 tensors through HBM for a few hundred FLOP per byte: as separate implicit-GEMM launches these layers
+// ran at 2-3x their HBM time (profiles/r01_gemm_shapes_v2.csv).  Here one workgroup
+//   1. loads the time slab it needs (256 + halo rows, channels-last fp16) into LDS once,
+//   2. runs the first convolution out of LDS (every tap is a row-shifted view of the same slab, so the
+//      im2col re-reads of the generic kernel disappear), applies its pointwise tail and leaves the 256-row
+//      intermediate in LDS (forward also streams it to HBM for the tape; backward never stores it),
+//   3. runs the second convolution from that intermediate, and
+//   4. finishes with the shared LDS-staged epilogue (residual / averaging / leaky-relu of the stored tensor).
+// HBM traffic per pair drops from 5 to 3 tensors (forward) and from 7 to 4 (backward).
+// The weights of one tap (C x C) stream through a 3-stage LDS ring, prefetched two taps ahead.
+// MFMA operand roles are the same as in gemm_conv.hip (weight = A operand), so the accumulator layout and
+// the epilogue are shared.  The same kernel with `single` set is a plain slab convolution.
+#include "gemm_epilogue.h"
+#include "conv_pair.h"
+
+namespace {
+
+constexpr int PAIR_HALO = 50;            // max (lo + hi) halo rows of one stage
+constexpr int PAIR_ROWS = 256;           // intermediate rows per workgroup
+constexpr unsigned PAIR_OOB = 0x80000000u;
+
+struct PairParams {
+  GemmDesc a, b;
+  int T, nb, BMo;                        // frames per clip, workgroups per clip, output rows per workgroup
+  int loA, hiA, loB, hiB;
+  int off0A, dA, off0B, dB;              // slab row read by tap j of a stage: off0 + j * d  (taps are affine: j*dil - pad or pad - j*dil)
+  int single;
+};
+
+template <int C>
+struct PairCfg {
+  // +32 B: a ds_read_b128 lane group is 8 rows at one k-quarter plus 8 other rows at the next (MI355X_MICROARCH.md, LDS);
+  // with a pitch of 2C+32 bytes (24 / 40 dwords) those 16 four-dword spans hit 16 different bank quads
+  static constexpr int PITCH = 2 * C + 32;
+  static constexpr int CPR = C / 8;                // 16-byte chunks per row
+  static constexpr int FN = C / 16;
+  static constexpr int TPS = 64 / C;               // taps per 64-deep K step
+  static constexpr int SLAB_ROWS = PAIR_ROWS + PAIR_HALO;
+  static constexpr int SLAB_BYTES = SLAB_ROWS * PITCH;
+  static constexpr int TILE = C * 128;             // weights of one K step: C rows x 64 k, 128-byte rows, XOR-swizzled chunks
+  static constexpr int NS = 3;
+  static constexpr int PER = TILE / 1024 / 4;      // LDS-DMA instructions per wave per K step
+  static constexpr int SLAB_IT = (SLAB_ROWS * CPR + 255) / 256;
+  static constexpr int BITS_BYTES = PAIR_ROWS * CPR;
+  static constexpr int LDS_BYTES = SLAB_BYTES + NS * TILE + BITS_BYTES;
+};
+
+template <int FN>
+struct PairFrags { frag8_t x[2][4]; frag8_t w[2][FN]; };
+
+#define DMX_PAIR_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+// the fragment reads are inline asm (the compiler would otherwise sink them next to their MFMAs and put a vmcnt(0) in front
+// of every LDS read that may alias an LDS-DMA target); this wait ties the registers so no consumer is scheduled above it
+__device__ __forceinline__ void pair_settle(PairFrags<4>& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[0][2]), "+v"(f.x[0][3]), "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[1][2]),
+                 "+v"(f.x[1][3]), "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[0][2]), "+v"(f.w[0][3]), "+v"(f.w[1][0]), "+v"(f.w[1][1]),
+                 "+v"(f.w[1][2]), "+v"(f.w[1][3])
+               :
+               : "memory");
+}
+__device__ __forceinline__ void pair_settle(PairFrags<2>& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(f.x[0][0]), "+v"(f.x[0][1]), "+v"(f.x[0][2]), "+v"(f.x[0][3]), "+v"(f.x[1][0]), "+v"(f.x[1][1]), "+v"(f.x[1][2]),
+                 "+v"(f.x[1][3]), "+v"(f.w[0][0]), "+v"(f.w[0][1]), "+v"(f.w[1][0]), "+v"(f.w[1][1])
+               :
+               : "memory");
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
+  using K = PairCfg<C>;
+  constexpr int PITCH = K::PITCH, CPR = K::CPR, FN = K::FN, NS = K::NS, PER = K::PER, TILE = K::TILE;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  char* ring = smem;                                   // 1 KiB-aligned LDS-DMA targets first
+  char* slab = smem + NS * TILE;
+  unsigned char* s_bits = reinterpret_cast<unsigned char*>(slab + K::SLAB_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bid = blockIdx.x;
+  {  // XCD-aware remap: neighbouring time tiles (shared halos, same weights) land on the same L2
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int T = P.T;
+  const int b = bid / P.nb, tq = bid - b * P.nb;
+  const int t0 = tq * P.BMo;
+  const bool single = P.single != 0;
+  const int kA = single ? 0 : P.a.ntaps, kB = P.b.ntaps;
+  const int stepsA = (kA * C + 63) / 64, stepsB = (kB * C + 63) / 64, total = stepsA + stepsB;
+
+  // ---- weights: one 64-deep K step (C rows x 128 B) per LDS-DMA tile, three tiles ahead of the MFMAs
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(single ? P.b.W : P.a.W), 0, PAIR_OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(P.b.W), 0, PAIR_OOB, 0x00020000);
+  const int lrow = lane >> 3, cc = (lane & 7) ^ lrow;   // lane fetches logical 16-B chunk cc of tile row (8j + lrow): swizzled image
+  auto issue_dma = [&](int g) {
+    const bool inA = g < stepsA;
+    const int sidx = inA ? g : g - stepsA;
+    const int Kel = inA ? P.a.K : P.b.K;
+    const unsigned ldw2 = (unsigned)(inA ? P.a.ldw : P.b.ldw) * 2u;
+    const int kel = sidx * 64 + cc * 8;
+    const bool ok = g < total && kel < Kel;
+    char* dst = ring + (g % NS) * TILE;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int j = i * 4 + wave;
+      const unsigned voff = ok ? (unsigned)(j * 8 + lrow) * ldw2 + (unsigned)kel * 2u : PAIR_OOB;
+      if (inA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff, 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+  issue_dma(0);
+  issue_dma(1);
+  issue_dma(2);
+
+  // ---- phase 1: time slab (zero outside the clip) and the leaky-relu' sign bits of the stage-A mask
+  {
+    const act_t* src = single ? P.b.A : P.a.A;
+    const int nrows = PAIR_ROWS + (single ? P.loB + P.hiB : P.loA + P.hiA);
+    const int tfirst = t0 - P.loB - (single ? 0 : P.loA);
+    uint4 sv[K::SLAB_IT];
+#pragma unroll
+    for (int it = 0; it < K::SLAB_IT; ++it) {
+      const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = tfirst + row;
+      sv[it] = make_uint4(0, 0, 0, 0);
+      if (row < nrows && t >= 0 && t < T) sv[it] = *reinterpret_cast<const uint4*>(src + ((long long)b * T + t) * C + piece * 8);
+    }
+    const bool masked = !single && (P.a.flags & EPI_MASK);
+    uint4 mv[CPR];
+    if (masked) {
+#pragma unroll
+      for (int it = 0; it < CPR; ++it) {
+        const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+        mv[it] = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < T) mv[it] = *reinterpret_cast<const uint4*>(P.a.X + ((long long)b * T + t) * C + piece * 8);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < K::SLAB_IT; ++it) {
+      const int c = tid + it * 256, row = c / CPR, piece = c % CPR;
+      if (row < K::SLAB_ROWS) *reinterpret_cast<uint4*>(slab + row * PITCH + piece * 16) = sv[it];
+    }
+    if (masked) {
+      auto pos2 = [](uint32_t u) -> unsigned {   // bit0: low half > 0, bit1: high half > 0   (fp16/bf16: sign clear and non-zero)
+        const unsigned lo = ((u & 0x8000u) == 0u) && ((u & 0x7fffu) != 0u);
+        const unsigned hi = ((u & 0x80000000u) == 0u) && ((u & 0x7fff0000u) != 0u);
+        return lo | (hi << 1);
+      };
+#pragma unroll
+      for (int it = 0; it < CPR; ++it) {
+        const int c = tid + it * 256;
+        s_bits[c] = (unsigned char)(pos2(mv[it].x) | (pos2(mv[it].y) << 2) | (pos2(mv[it].z) << 4) | (pos2(mv[it].w) << 6));
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[4][FN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  using Frags = PairFrags<FN>;
+  const unsigned xlane = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(slab + (wave * 64 + lr) * PITCH + lq * 16);
+  const unsigned wlane0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + lr * 128 + (((0 * 4 + lq) ^ (lr & 7)) << 4));
+  const unsigned wlane1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + lr * 128 + (((1 * 4 + lq) ^ (lr & 7)) << 4));
+  // fragments of K step s of a stage (global step g): x rows shifted by the tap, weights from ring tile g
+  auto load_frags = [&](Frags& f, bool isB, int sidx, int g) {
+    const int off0 = isB ? P.off0B : P.off0A, dd = isB ? P.dB : P.dA, kk = isB ? kB : kA;
+    unsigned xa0, xa1;
+    if constexpr (C == 64) {
+      xa0 = xlane + (unsigned)((off0 + sidx * dd) * PITCH);
+      xa1 = xa0 + 64u;
+    } else {
+      const int tp0 = 2 * sidx, tp1 = (2 * sidx + 1 < kk) ? 2 * sidx + 1 : kk - 1;   // a padded tap has zero weights: any valid rows
+      xa0 = xlane + (unsigned)((off0 + tp0 * dd) * PITCH);
+      xa1 = xlane + (unsigned)((off0 + tp1 * dd) * PITCH);
+    }
+    const unsigned wo = (unsigned)((g % NS) * TILE);
+    const unsigned wa0 = wlane0 + wo, wa1 = wlane1 + wo;
+    static_for<0, 4>([&f, xa0, xa1](auto I) {
+      constexpr int i = decltype(I)::value;
+      DMX_PAIR_DSR(f.x[0][i], xa0, i * 16 * PITCH);
+      DMX_PAIR_DSR(f.x[1][i], xa1, i * 16 * PITCH);
+    });
+    static_for<0, FN>([&f, wa0, wa1](auto N) {
+      constexpr int n = decltype(N)::value;
+      DMX_PAIR_DSR(f.w[0][n], wa0, n * 2048);
+      DMX_PAIR_DSR(f.w[1][n], wa1, n * 2048);
+    });
+  };
+  auto mfma_block = [&](const Frags& f) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < FN; ++n) acc[i][n] = DMX_MFMA16(f.w[ks][n], f.x[ks][i], acc[i][n]);
+  };
+  // one K step: the next step's fragments and the weight tile three steps ahead are in flight under this step's MFMAs
+  auto step = [&](Frags& cur, Frags& nxt, bool isB, int sidx, int n, int g) {
+    issue_dma(g + 3);
+    const bool more = sidx + 1 < n;
+    if (more) load_frags(nxt, isB, sidx + 1, g + 1);
+    mfma_block(cur);
+    if (more) pair_settle(nxt);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");      // tile g+2 has landed (tile g+3 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+  };
+  auto run_stage = [&](bool isB, int n, int g0) {
+    Frags fa, fb;
+    load_frags(fa, isB, 0, g0);
+    pair_settle(fa);
+    for (int sidx = 0; sidx < n; sidx += 2) {
+      step(fa, fb, isB, sidx, n, g0 + sidx);
+      if (sidx + 1 < n) step(fb, fa, isB, sidx + 1, n, g0 + sidx + 1);
+    }
+  };
+
+  if (!single) {
+    // ---- stage A: 256 intermediate rows, row i <-> t = t0 - loB + i
+    zero_acc();
+    run_stage(false, stepsA, 0);
+    // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
+    const int fa = P.a.flags;
+    const float aslope = P.a.act_slope, mslope = P.a.mask_slope;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wave * 64 + i * 16 + lr;
+      const int t = t0 - P.loB + row;
+      const bool inside = t >= 0 && t < T;
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const int ch = n * 16 + lq * 4;
+        float v[4] = {acc[i][n][0], acc[i][n][1], acc[i][n][2], acc[i][n][3]};
+        if (fa & EPI_MASK) {
+          const unsigned bits = (unsigned)s_bits[row * CPR + (ch >> 3)] >> (ch & 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : mslope;
+        }
+        if (fa & EPI_BIAS) {
+          const float4 bb = *reinterpret_cast<const float4*>(P.a.bias + ch);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
+        if (fa & EPI_LRELU2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * aslope;
+        }
+        if (!inside) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+        *reinterpret_cast<uint2*>(slab + row * PITCH + ch * 2) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
+      }
+    }
+    __syncthreads();
+    if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only, full rows
+#pragma unroll
+      for (int it = 0; it < CPR; ++it) {
+        const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+        if (row >= P.loB && row < P.loB + P.BMo && t < T)
+          *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
+      }
+    }
+  }
+
+  // ---- stage B: output row r <-> t = t0 + r reads intermediate rows r + (tap offset + loB)
+  zero_acc();
+  run_stage(true, stepsB, stepsA);
+  __syncthreads();
+  {
+    constexpr int EPI_WAVE_BYTES = 64 * (FN * 32 + 16) + 64 * 12;
+    static_assert(EPI_WAVE_BYTES * 4 <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
+    const int mbase = b * T + t0;
+    const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
+    gemm_epilogue_lds<4, FN>(P.b, acc, mbase + wave * 64, 0, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend);
+  }
+}
+
+struct Halo { int lo, hi; bool ok; int d; };
+Halo halo_of(const GemmDesc& d) {
+  Halo h{0, 0, true, d.ntaps > 1 ? d.tdx[1] - d.tdx[0] : 0};
+  for (int j = 0; j < d.ntaps; ++j) {
+    if (d.tdx[j] != d.tdx[0] + j * h.d) h.ok = false;      // taps must be affine in j
+    if (d.tdy[j] != 0) h.ok = false;
+    if (-d.tdx[j] > h.lo) h.lo = -d.tdx[j];
+    if (d.tdx[j] > h.hi) h.hi = d.tdx[j];
+  }
+  if (h.lo + h.hi > PAIR_HALO) h.ok = false;
+  return h;
+}
+
+bool stage_ok(const GemmDesc& d, int C, int T, int allowed_flags) {
+  if (d.N != C || d.Ci != C || d.lda != C || d.K != d.ntaps * C || d.ldw < d.K) return false;
+  if (d.ntaps < 1 || d.ntaps > 16 || d.Z != 1 || d.Hq != 1 || d.Hi != 1 || d.Ho != 1) return false;
+  if (d.Wq != T || d.Wi != T || d.Wo != T || d.sx != 1 || d.osx != 1 || d.oox != 0 || d.ooy != 0) return false;
+  if (d.flags & ~allowed_flags) return false;
+  if (d.M % T != 0) return false;
+  return true;
+}
+
+bool g_pair_enabled = getenv("DMX_NO_PAIR") == nullptr;
+
+}  // namespace
+
+bool dmx_conv_pair_eligible(const GemmDesc* a, const GemmDesc& b) {
+  if (!g_pair_enabled) return false;
+  const int C = b.N, T = b.Wq;
+  if (C != 32 && C != 64) return false;
+  if (T < 1) return false;
+  const int bflags = EPI_BIAS | EPI_RESID | EPI_RESID_INV | EPI_ACCUM | EPI_MASK | EPI_LRELU2 | EPI_NO_C;
+  if (!stage_ok(b, C, T, bflags) || !halo_of(b).ok) return false;
+  if (b.ldc != C || ((b.flags & EPI_RESID) && b.ldr != C) || ((b.flags & EPI_MASK) && b.ldx != C) || ((b.flags & EPI_LRELU2) && b.ldc2 != C))
+    return false;
+  if (a) {
+    if (!stage_ok(*a, C, T, EPI_BIAS | EPI_LRELU2 | EPI_NO_C | EPI_MASK) || !halo_of(*a).ok) return false;
+    if (a->M != b.M || a->alpha != 1.f) return false;
+    if ((a->flags & EPI_LRELU2) && (a->ldc2 != C || !a->C2)) return false;
+    if ((a->flags & EPI_MASK) && (a->ldx != C || !a->X)) return false;
+    const Halo hb = halo_of(b);
+    if (PAIR_ROWS - hb.lo - hb.hi < 128) return false;
+  }
+  return true;
+}
+
+// a == nullptr: plain slab convolution of `b`.  Otherwise b.A must be the tensor stage `a` produces
+// (a.C2 when a carries EPI_LRELU2, else a.C); it is taken from LDS and, in the latter case, never written.
+int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
+  if (!dmx_conv_pair_eligible(a, b)) return DMX_ERR_SHAPE;
+  PairParams P;
+  memset(&P, 0, sizeof(P));
+  P.b = b;
+  P.single = a ? 0 : 1;
+  if (a) P.a = *a;
+  const Halo hb = halo_of(b);
+  P.loB = hb.lo; P.hiB = hb.hi;
+  P.off0B = b.tdx[0] + hb.lo; P.dB = hb.d;
+  if (a) { const Halo ha = halo_of(*a); P.loA = ha.lo; P.hiA = ha.hi; P.off0A = a->tdx[0] + ha.lo; P.dA = ha.d; }
+  P.T = b.Wq;
+  P.BMo = a ? PAIR_ROWS - hb.lo - hb.hi : PAIR_ROWS;
+  P.nb = cdiv(P.T, P.BMo);
+  const int nclips = b.M / P.T;
+  const long long grid = (long long)nclips * P.nb;
+  if (grid > 0x7fffffffLL) return DMX_ERR_SHAPE;
+  const int C = b.N;
+  double fl = 2.0 * b.M * (double)b.N * b.K;
+  double by = 2.0 * b.M * (double)C * 2.0;                     // input + output
+  if (a) { fl += 2.0 * a->M * (double)a->N * a->K; if (a->flags & EPI_LRELU2) by += 2.0 * b.M * (double)C; if (a->flags & EPI_MASK) by += 2.0 * b.M * (double)C; }
+  if (b.flags & EPI_RESID) by += 2.0 * b.M * (double)C;
+  if (b.flags & EPI_MASK) by += 2.0 * b.M * (double)C;
+  if (b.flags & EPI_ACCUM) by += 2.0 * b.M * (double)C;
+  if ((b.flags & EPI_LRELU2) && !(b.flags & EPI_NO_C)) by += 2.0 * b.M * (double)C;
+  const int rec = dmx_prof_open(st);
+  if (C == 32) {
+    static bool attr32 = false;
+    if (!attr32) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<32>::LDS_BYTES); attr32 = true; }
+    hipLaunchKernelGGL(conv_pair_kernel<32>, dim3((unsigned)grid), dim3(256), PairCfg<32>::LDS_BYTES, st, P);
+  } else {
+    static bool attr64 = false;
+    if (!attr64) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<64>::LDS_BYTES); attr64 = true; }
+    hipLaunchKernelGGL(conv_pair_kernel<64>, dim3((unsigned)grid), dim3(256), PairCfg<64>::LDS_BYTES, st, P);
+  }
+  dmx_prof_close(rec, st, fl, by, b.M, b.N, (a ? a->K : 0) + b.K, b.ntaps, b.flags, a ? 21 : 20);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}

@@ -1,0 +1,233 @@
+// Fused GEMM epilogues shared by the implicit-GEMM kernels (gemm_conv.hip) and the fused resblock-pair kernel
+// (conv_pair.hip).  Device-only; include inside a .hip translation unit.
+#pragma once
+#include "dmx_common.h"
+#include <type_traits>
+
+namespace {
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+
+// Fused epilogue shared by both kernels: lane holds n = n0 + j*16 + 4*lq + {0..3} for pixel row m = m0 + i*16 + lr.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lr, int lq,
+                                              long long coff, int HqWq) {
+  const int flags = p.flags;
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = m0 + i * 16 + lr;
+    if (m >= p.M) continue;
+    const int b = m / HqWq, rem = m - b * HqWq;
+    const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+    const long long orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + j * 16 + lq * 4;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (flags & EPI_MASK) {
+        const uint2 xr = *reinterpret_cast<const uint2*>(p.X + coff + orow * p.ldx + n);
+        const float s = p.mask_slope;
+        v[0] *= (alo(xr.x) > 0.f) ? 1.f : s;
+        v[1] *= (ahi(xr.x) > 0.f) ? 1.f : s;
+        v[2] *= (alo(xr.y) > 0.f) ? 1.f : s;
+        v[3] *= (ahi(xr.y) > 0.f) ? 1.f : s;
+      }
+      if (flags & EPI_BIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_ROWBIAS) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * p.N + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (flags & EPI_RESID) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.R + coff + orow * p.ldr + n);
+        float r0 = alo(rr.x), r1 = ahi(rr.x), r2 = alo(rr.y), r3 = ahi(rr.y);
+        if (flags & EPI_RESID_INV) {
+          const float is = p.resid_inv_slope;
+          r0 = r0 > 0.f ? r0 : r0 * is; r1 = r1 > 0.f ? r1 : r1 * is; r2 = r2 > 0.f ? r2 : r2 * is; r3 = r3 > 0.f ? r3 : r3 * is;
+        }
+        v[0] += r0; v[1] += r1; v[2] += r2; v[3] += r3;
+      }
+      const float al = p.alpha;
+      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+      if (flags & EPI_F32OUT) {
+        float* cp = reinterpret_cast<float*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const float4 o = *reinterpret_cast<const float4*>(cp);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        act_t* cp = reinterpret_cast<act_t*>(p.C) + coff + orow * p.ldc + n;
+        if (flags & EPI_ACCUM) {
+          const uint2 o = *reinterpret_cast<const uint2*>(cp);
+          v[0] += alo(o.x); v[1] += ahi(o.x); v[2] += alo(o.y); v[3] += ahi(o.y);
+        }
+        if (flags & EPI_TANH) { v[0] = tanhf(v[0]); v[1] = tanhf(v[1]); v[2] = tanhf(v[2]); v[3] = tanhf(v[3]); }
+        if (!(flags & EPI_NO_C)) *reinterpret_cast<uint2*>(cp) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
+      }
+      if (flags & EPI_LRELU2) {
+        const float s = p.act_slope;
+        const float a0 = v[0] > 0.f ? v[0] : v[0] * s, a1 = v[1] > 0.f ? v[1] : v[1] * s;
+        const float a2 = v[2] > 0.f ? v[2] : v[2] * s, a3 = v[3] > 0.f ? v[3] : v[3] * s;
+        *reinterpret_cast<uint2*>(p.C2 + coff + orow * p.ldc2 + n) = make_uint2(pack2a(a0, a1), pack2a(a2, a3));
+      }
+    }
+  }
+}
+
+// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM)
+template <int FM>
+struct EpiChunk { static constexpr int IB = (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 3 : (FM % 2 == 0) ? 2 : 1; static constexpr int CH = IB * 16; };
+
+// ---------------------------------------------------------------------------------------------
+// LDS-staged epilogue for fp16 outputs.  The MFMA accumulator layout gives a lane 4 channels of one pixel
+// (8-byte pieces, 32-byte runs per row); written straight to HBM that is 1/4 of a cache line per row and the
+// epilogue ran at ~2 TB/s, 35-65 % of a HiFi-GAN layer's time.  Here every tensor the epilogue touches (mask
+// source X, residual R, previous C, outputs C and C2) moves between HBM and a wave-private LDS tile in full
+// row segments (16 B per lane, TN*2-byte contiguous runs = whole cache lines) and is exchanged with the
+// accumulator layout through LDS.  Rows are handled in chunks of CH <= 64 to fit 8 waves in the stage buffers.
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
+                                                  long long coff, int HqWq, char* wl, int mlimit = 0x7fffffff) {
+  constexpr int CH = EpiChunk<FM>::CH;
+  constexpr int IB = EpiChunk<FM>::IB;
+  constexpr int TNB = FN * 32;            // bytes per tile row
+  constexpr int PITCH = TNB + 16;
+  constexpr int CPR = TNB / 16;           // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;           // rows per wave-instruction in the row-major phase
+  const int lr = lane & 15, lq = lane >> 4;
+  const int rr = lane / CPR, cch = lane - rr * CPR;
+  long long* tab = reinterpret_cast<long long*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range)
+  int* tabb = reinterpret_cast<int*>(wl + CH * PITCH + CH * 8);      // batch image per tile row
+  const int flags = p.flags;
+  const int ncol = n0 + cch * 8;
+  const bool col_ok = ncol < p.N;
+#define DMX_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#pragma unroll
+  for (int h = 0; h < FM / IB; ++h) {
+    if (lq == 0) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const int m = m0 + (h * IB + ii) * 16 + lr;
+        long long orow = -1;
+        int b = 0;
+        if (m < p.M && m < mlimit) {
+          b = m / HqWq;
+          const int rem = m - b * HqWq;
+          const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
+          orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+        }
+        tab[ii * 16 + lr] = orow;
+        tabb[ii * 16 + lr] = b;
+      }
+    }
+    DMX_LDS_SYNC();
+    // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`
+    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
+#pragma unroll
+      for (int r0 = 0; r0 < CH; r0 += RPI) {
+        const int row = r0 + rr;
+        const long long orow = tab[row];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (orow >= 0 && col_ok) v = *reinterpret_cast<const uint4*>(G + coff + orow * ld + ncol);
+        *reinterpret_cast<uint4*>(wl + row * PITCH + cch * 16) = v;
+      }
+      DMX_LDS_SYNC();
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const uint2 q = *reinterpret_cast<const uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2);
+          f(acc[h * IB + ii][j], alo(q.x), ahi(q.x), alo(q.y), ahi(q.y));
+        }
+      DMX_LDS_SYNC();
+    };
+    auto stage_out = [&](act_t* G, int ld, auto&& f) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          float o[4];
+          f(acc[h * IB + ii][j], o);
+          *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
+        }
+      DMX_LDS_SYNC();
+#pragma unroll
+      for (int r0 = 0; r0 < CH; r0 += RPI) {
+        const int row = r0 + rr;
+        const long long orow = tab[row];
+        const uint4 v = *reinterpret_cast<const uint4*>(wl + row * PITCH + cch * 16);
+        if (orow >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + orow * ld + ncol) = v;
+      }
+      DMX_LDS_SYNC();
+    };
+    if (flags & EPI_MASK) {
+      const float sl = p.mask_slope;
+      stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+        a[0] *= x0 > 0.f ? 1.f : sl; a[1] *= x1 > 0.f ? 1.f : sl; a[2] *= x2 > 0.f ? 1.f : sl; a[3] *= x3 > 0.f ? 1.f : sl;
+      });
+    }
+    if (flags & (EPI_BIAS | EPI_ROWBIAS)) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + j * 16 + lq * 4;
+          if (n >= p.N) continue;
+          f32x4& a = acc[h * IB + ii][j];
+          if (flags & EPI_BIAS) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+            a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+          }
+          if (flags & EPI_ROWBIAS) {
+            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)tabb[ii * 16 + lr] * p.N + n);
+            a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+          }
+        }
+    }
+    if (flags & EPI_RESID) {
+      const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
+      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+        a[0] += x0 > 0.f ? x0 : x0 * is; a[1] += x1 > 0.f ? x1 : x1 * is; a[2] += x2 > 0.f ? x2 : x2 * is; a[3] += x3 > 0.f ? x3 : x3 * is;
+      });
+    }
+    {
+      const float al = p.alpha;
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] *= al; a[1] *= al; a[2] *= al; a[3] *= al; }
+    }
+    if (flags & EPI_ACCUM)
+      stage_in(reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+    if (flags & EPI_TANH) {
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
+    }
+    if (!(flags & EPI_NO_C))
+      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+    if (flags & EPI_LRELU2) {
+      const float sl = p.act_slope;
+      stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
+        o[0] = a[0] > 0.f ? a[0] : a[0] * sl; o[1] = a[1] > 0.f ? a[1] : a[1] * sl;
+        o[2] = a[2] > 0.f ? a[2] : a[2] * sl; o[3] = a[3] > 0.f ? a[3] : a[3] * sl;
+      });
+    }
+  }
+#undef DMX_LDS_SYNC
+}
+
+}  // namespace

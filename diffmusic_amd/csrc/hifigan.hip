@@ -133,21 +133,24 @@ struct HifiGan : Model {
         hipStream_t sk = (mt && k > 0) ? bstream[k] : st;
         for (int d = 0; d < nd; ++d) {
           const int id = idx(s, k, d);
+          GemmDesc da, db;
           {
             Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = ha[id];
-            RUN(conv_fwd_1d(c1[id], xa[id], ha[id], B, To, e, sk));
+            RUN(conv_fwd_1d_desc(c1[id], xa[id], ha[id], B, To, e, da));
           }
           if (d < nd - 1) {
             act_t* xn = xa[idx(s, k, d + 1)];
             Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
             e.act_slope = slope; e.C2 = xn;
-            RUN(conv_fwd_1d(c2[id], ha[id], xn, B, To, e, sk));
+            RUN(conv_fwd_1d_desc(c2[id], ha[id], xn, B, To, e, db));
+            RUN(conv_pair_run(da, db, sk));
           } else {
             Epi e; e.flags = EPI_RESID | EPI_RESID_INV; e.R = xa[id]; e.resid_inv_slope = 1.f / slope; e.alpha = 1.f / nk;
             if (k > 0) e.flags |= EPI_ACCUM;
             if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
             if (mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order
-            RUN(conv_fwd_1d(c2[id], ha[id], sum, B, To, e, sk));
+            RUN(conv_fwd_1d_desc(c2[id], ha[id], sum, B, To, e, db));
+            RUN(conv_pair_run(da, db, sk));
             if (mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
           }
         }
@@ -207,9 +210,10 @@ struct HifiGan : Model {
         const act_t* gc = g;
         for (int d = nd - 1; d >= 0; --d) {
           const int id = idx(s, k, d);
+          GemmDesc da, db;
           {
             Epi e; e.flags = EPI_MASK; e.X = ha[id]; e.mask_slope = slope;
-            RUN(conv_bwd_1d(c2[id], gc, ghk[k], B, To, e, sk));
+            RUN(conv_bwd_1d_desc(c2[id], gc, ghk[k], B, To, e, da));
           }
           Epi e; e.flags = EPI_MASK | EPI_RESID; e.X = xa[id]; e.mask_slope = slope; e.R = gc;
           act_t* dst;
@@ -220,7 +224,8 @@ struct HifiGan : Model {
           } else {
             dst = (gc == gAB[k][0]) ? gAB[k][1] : gAB[k][0];
           }
-          RUN(conv_bwd_1d(c1[id], ghk[k], dst, B, To, e, sk));
+          RUN(conv_bwd_1d_desc(c1[id], ghk[k], dst, B, To, e, db));
+          RUN(conv_pair_run(da, db, sk));
           if (d == 0 && mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
           gc = dst;
         }

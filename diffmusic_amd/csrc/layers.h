@@ -88,6 +88,10 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st);
 int conv_out_len(const ConvLayer& L, int Ti);
 int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, hipStream_t st);
 int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, hipStream_t st);
+// descriptor-only builders (stride-1, non-transposed) and the fused two-stage launch used by the HiFi-GAN resblocks
+int conv_fwd_1d_desc(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, GemmDesc& d);
+int conv_bwd_1d_desc(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, GemmDesc& d);
+int conv_pair_run(const GemmDesc& a, const GemmDesc& b, hipStream_t st);
 int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 int conv_bwd_2d(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 // plain (batched) NT GEMM: C[z] = alpha * A[z] (M,K; lda) * Bm[z]^T (N,K; ldb)  (+ epilogue)

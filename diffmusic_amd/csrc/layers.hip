@@ -1,5 +1,6 @@
 // Parameter registry, weight packing and GemmDesc builders (see layers.h).
 #include "layers.h"
+#include "conv_pair.h"
 #include <cstdarg>
 
 static thread_local char g_err[512] = "";
@@ -168,20 +169,31 @@ int conv_out_len(const ConvLayer& L, int Ti) {
   return (Ti + 2 * L.pad_w - L.dil * (L.kw - 1) - 1) / L.stride + 1;
 }
 
-int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, hipStream_t st) {
-  const int To = conv_out_len(L, Ti);
-  GemmDesc d;
+static void fwd_1d_common(GemmDesc& d, const ConvLayer& L, const act_t* in, void* out, int Ti, int To, const Epi& e) {
   init_desc(d, e);
   if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
   d.A = in; d.Hi = 1; d.Wi = Ti; d.Ci = L.Cip; d.lda = L.Cip;
   d.N = L.Cop;
   set_out(d, out, 1, To, L.Cop);
+}
+int conv_fwd_1d_desc(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, GemmDesc& d) {
+  if (L.transposed) return DMX_ERR_SHAPE;
+  const int To = conv_out_len(L, Ti);
+  fwd_1d_common(d, L, in, out, Ti, To, e);
+  d.W = L.wf[0]; d.ntaps = L.kw; d.K = L.kw * L.Cip; d.ldw = d.K;
+  d.Hq = 1; d.Wq = To; d.sx = L.stride; d.M = B * To;
+  for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(t * L.dil - L.pad_w); }
+  return DMX_OK;
+}
+
+int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, const Epi& e, hipStream_t st) {
+  const int To = conv_out_len(L, Ti);
+  GemmDesc d;
   if (!L.transposed) {
-    d.W = L.wf[0]; d.ntaps = L.kw; d.K = L.kw * L.Cip; d.ldw = d.K;
-    d.Hq = 1; d.Wq = To; d.sx = L.stride; d.M = B * To;
-    for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(t * L.dil - L.pad_w); }
-    return dmx_gemm_launch(d, st);
+    const int rc = conv_fwd_1d_desc(L, in, out, B, Ti, e, d);
+    return rc != DMX_OK ? rc : dmx_gemm_launch(d, st);
   }
+  fwd_1d_common(d, L, in, out, Ti, To, e);
   const int s = L.stride, p = L.pad_w;
   for (int r = 0; r < s; ++r) {
     GemmDesc q = d;
@@ -199,10 +211,9 @@ int conv_fwd_1d(const ConvLayer& L, const act_t* in, void* out, int B, int Ti, c
 }
 
 // dgrad: dout (B, To, Cop) -> din (B, Ti, Cip)
-int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, hipStream_t st) {
+int conv_bwd_1d_desc(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, GemmDesc& d) {
   if (!L.wb) { dmx_set_error("layer has no dgrad weights"); return DMX_ERR_STATE; }
   const int To = conv_out_len(L, Ti);
-  GemmDesc d;
   init_desc(d, e);
   d.A = dout; d.Hi = 1; d.Wi = To; d.Ci = L.Cop; d.lda = L.Cop;
   d.W = L.wb; d.ntaps = L.kw; d.K = L.kw * L.Cop; d.ldw = d.K;
@@ -216,7 +227,19 @@ int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti,
     d.sx = L.stride;
     for (int t = 0; t < L.kw; ++t) { d.tdy[t] = 0; d.tdx[t] = (signed char)(t - L.pad_w); }
   }
-  return dmx_gemm_launch(d, st);
+  return DMX_OK;
+}
+int conv_bwd_1d(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, hipStream_t st) {
+  GemmDesc d;
+  const int rc = conv_bwd_1d_desc(L, dout, din, B, Ti, e, d);
+  return rc != DMX_OK ? rc : dmx_gemm_launch(d, st);
+}
+
+// stage `a` then stage `b` (b.A is what a produces): one fused launch when the pair kernel takes the shape, else two launches
+int conv_pair_run(const GemmDesc& a, const GemmDesc& b, hipStream_t st) {
+  if (dmx_conv_pair_eligible(&a, b)) return dmx_conv_pair_launch(&a, b, st);
+  const int rc = dmx_gemm_launch(a, st);
+  return rc != DMX_OK ? rc : dmx_gemm_launch(b, st);
 }
 
 int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {

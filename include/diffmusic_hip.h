@@ -178,11 +178,14 @@ int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, 
 /* ---- measurement hooks: HIP events around every implicit-GEMM launch (bench.py roofline leg) ---------- */
 void dmx_prof_begin(void);
 int dmx_prof_end(double* total_ms, double* total_flops); /* returns the number of launches recorded */
-/* of the region closed by the last dmx_prof_end: launches / kernel ms / FLOPs of gemm_glds_kernel (LDS-DMA tiles) alone */
-int dmx_prof_dominant(double* ms, double* flops);
+/* of the region closed by the last dmx_prof_end: launches / kernel ms / FLOPs / algorithmic operand bytes of gemm_glds_kernel (LDS-DMA tiles) alone */
+int dmx_prof_dominant(double* ms, double* flops, double* bytes);
 
 /* ---- low-level test hook: one implicit-GEMM launch described by the internal descriptor --------*/
 int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
+/* test hook for the fused convolution pair (HiFi-GAN resblock step, C = 32 / 64): stage `a` (may be NULL: plain slab
+ * convolution) feeds stage `b` through LDS.  Returns DMX_ERR_SHAPE when the shape is not handled by the fused kernel. */
+int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes, void* stream);
 
 #ifdef __cplusplus
 }

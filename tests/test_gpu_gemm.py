@@ -121,3 +121,110 @@ def test_forced_tile_configs_agree(cfg):
     _run(L, d)
     ref = F.conv1d(x.float().transpose(1, 2), w.float(), None, padding=pad, dilation=dil).transpose(1, 2) + res.float()
     assert _rel(out, ref) < 3e-3
+
+
+def _conv_desc(L, x, wp, k, dil, Cc, B, T, flip=False, **kw):
+    pad = (k * dil - dil) // 2
+    tdx = [(pad - t * dil) if flip else (t * dil - pad) for t in range(k)]
+    return _desc(L, A=x, W=wp, M=B * T, N=Cc, K=k * Cc, ldw=k * Cc, Hi=1, Wi=T, Ci=Cc, lda=Cc, Hq=1, Wq=T, ntaps=k, Ho=1, Wo=T,
+                 ldc=Cc, ldr=Cc, ldx=Cc, ldc2=Cc, tdy=[0] * k, tdx=tdx, **kw)
+
+
+def _pair_run(L, da, db):
+    L.check(L.lib().dmx_conv_pair_raw(C.byref(da) if da is not None else None, C.byref(db), C.sizeof(db),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)), "conv_pair")
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,T,Cc,k,dil", [(2, 1000, 64, 3, 1), (1, 2049, 64, 11, 5), (3, 700, 32, 7, 3), (2, 5000, 32, 11, 5),
+                                          (1, 100, 32, 3, 1), (2, 256, 64, 7, 1), (1, 4097, 64, 3, 5)])
+def test_fused_resblock_pair_forward(B, T, Cc, k, dil):
+    """conv1(dilated) -> leaky-relu -> conv2 -> + reconstructed residual, the HiFi-GAN resblock step
+    (modeling_speecht5.py HifiGanResidualBlock.forward), fused in one launch; checked against torch fp32 and
+    against the same two stages run as separate implicit-GEMM launches."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(3)
+    slope = 0.1
+    xa = F.leaky_relu(torch.randn(B, T, Cc, generator=g), slope).to(_adt()).cuda()       # the stored (activated) residual stream
+    w1 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    w2 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    b1, b2 = torch.randn(Cc, generator=g).cuda() * 0.1, torch.randn(Cc, generator=g).cuda() * 0.1
+    w1p = w1.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    w2p = w2.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    outs = {}
+    for mode in ("fused", "separate"):
+        ha = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+        xn = torch.zeros_like(ha)
+        raw = torch.zeros_like(ha)
+        da = _conv_desc(L, xa, w1p, k, dil, Cc, B, T, C=ha, C2=ha, bias=b1, flags=L.EPI_BIAS | L.EPI_LRELU2 | L.EPI_NO_C, act_slope=slope)
+        db = _conv_desc(L, ha, w2p, k, 1, Cc, B, T, C=raw, C2=xn, bias=b2, R=xa, resid_inv_slope=1.0 / slope, act_slope=slope,
+                        flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_RESID_INV | L.EPI_LRELU2)
+        if mode == "fused":
+            _pair_run(L, da, db)
+        else:
+            _run(L, da)
+            _run(L, db)
+        outs[mode] = (ha, raw, xn)
+    x = torch.where(xa.float() > 0, xa.float(), xa.float() / slope)
+    h = F.leaky_relu(F.conv1d(xa.float().transpose(1, 2), w1.float(), b1, padding=(k * dil - dil) // 2, dilation=dil), slope)
+    hq = h.to(_adt()).float()
+    y = F.conv1d(hq, w2.float(), b2, padding=(k - 1) // 2).transpose(1, 2) + x
+    ha, raw, xn = outs["fused"]
+    assert _rel(ha, h.transpose(1, 2)) < 4e-3
+    assert _rel(raw, y) < 6e-3
+    assert _rel(xn, F.leaky_relu(y, slope)) < 6e-3
+    for a, b in zip(outs["fused"], outs["separate"]):
+        assert _rel(a, b) < 2e-3
+
+
+@pytest.mark.parametrize("B,T,Cc,k,dil", [(2, 1000, 64, 3, 1), (1, 2049, 64, 11, 5), (3, 700, 32, 7, 3), (2, 3000, 32, 11, 5),
+                                          (1, 100, 64, 7, 5)])
+def test_fused_resblock_pair_backward(B, T, Cc, k, dil):
+    """dgrad(conv2) -> leaky-relu' -> dgrad(conv1) -> leaky-relu' + residual, accumulated into an existing gradient."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(4)
+    slope = 0.1
+    gc = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    ha = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    xa = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    prev = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    w1 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    w2 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    w1b = w1.permute(1, 2, 0).reshape(Cc, k * Cc).contiguous()          # dgrad packing: [Cin][tap][Cout]
+    w2b = w2.permute(1, 2, 0).reshape(Cc, k * Cc).contiguous()
+    outs = {}
+    for mode in ("fused", "separate"):
+        ghk = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+        dst = prev.clone()
+        da = _conv_desc(L, gc, w2b, k, 1, Cc, B, T, flip=True, C=ghk, X=ha, flags=L.EPI_MASK, mask_slope=slope)
+        db = _conv_desc(L, ghk, w1b, k, dil, Cc, B, T, flip=True, C=dst, X=xa, R=gc, mask_slope=slope,
+                        flags=L.EPI_MASK | L.EPI_RESID | L.EPI_ACCUM)
+        if mode == "fused":
+            _pair_run(L, da, db)
+        else:
+            _run(L, da)
+            _run(L, db)
+        outs[mode] = dst
+    gcf = gc.float().transpose(1, 2)
+    m_h = torch.where(ha.float() > 0, 1.0, slope).transpose(1, 2)
+    m_x = torch.where(xa.float() > 0, 1.0, slope).transpose(1, 2)
+    g1 = F.conv_transpose1d(gcf, w2.float(), padding=(k - 1) // 2) * m_h
+    g1 = g1.to(_adt()).float()
+    g0 = F.conv_transpose1d(g1, w1.float(), padding=(k * dil - dil) // 2, dilation=dil) * m_x + gcf
+    ref = g0.transpose(1, 2) + prev.float()
+    assert _rel(outs["fused"], ref) < 6e-3
+    assert _rel(outs["fused"], outs["separate"]) < 3e-3
+
+
+def test_slab_conv_single_stage():
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, T, Cc, k, dil = 2, 1500, 64, 7, 3
+    x = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    bias = torch.randn(Cc, generator=g).cuda()
+    out = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+    d = _conv_desc(L, x, w.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous(), k, dil, Cc, B, T, C=out, bias=bias, flags=L.EPI_BIAS)
+    _pair_run(L, None, d)
+    ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias, padding=(k * dil - dil) // 2, dilation=dil).transpose(1, 2)
+    assert _rel(out, ref) < 4e-3
