@@ -468,6 +468,10 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 8: return launch_glds<192, 256, 2, 4, 2>(d, stream);
     case 9: return launch_glds<320, 128, 4, 2, 2>(d, stream);
     case 10: return launch_glds<192, 128, 4, 2, 3>(d, stream);
+    case 11: return launch_glds<128, 128, 2, 2, 2>(d, stream);   // 4-wave LDS-DMA tiles for the small-M U-Net / VAE-mid GEMMs
+    case 12: return launch_glds<64, 64, 2, 2, 4>(d, stream);
+    case 13: return launch_glds<128, 64, 2, 2, 3>(d, stream);
+    case 14: return launch_glds<64, 128, 2, 2, 3>(d, stream);
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -477,7 +481,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 10 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 14 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   // measured best configuration for the shapes of the shipped benchmark configs (scripts/dev/tune_tiles.py)
   for (const TileEntry* e = g_tile_table; e->cfg; ++e)
     if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && ((e->cfg > 2 && e->cfg < 7) || gl)) return launch_by_cfg(e->cfg, d, stream);
@@ -542,7 +546,7 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
     if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
-    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10);          // gemm_glds_kernel (LDS-DMA tiles)
+    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 14);          // gemm_glds_kernel (LDS-DMA tiles)
     if (dma) { g_dma_ms += t; g_dma_fl += r.flops; g_dma_by += r.bytes; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
