@@ -86,6 +86,7 @@ _SIGS = {
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dmx_flash_attn_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p]),
     "dmx_conv_pair_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -6,6 +6,7 @@
 // temporaries and releases back to the mark.  Launches are stream-ordered, so a released temporary
 // may be handed out again to a later launch without a hazard.
 #pragma once
+#include <cstdlib>
 #include "models.h"
 
 struct Ctx {           // per-call execution context
@@ -140,6 +141,16 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
   const size_t mk = A.mark();
   // scores are written by the GEMM epilogue as fp16 straight into the P buffer (row pitch Nkp) and soft-maxed in place:
   // half the HBM traffic of an fp32 score matrix (the N = 1000 U-Net levels are write-bound on it)
+  static const bool fused_ok = getenv("DMX_NO_FLASH") == nullptr;
+  if (!P_keep && fused_ok && dmx_flash_attn_ok(dh, C, Nkp)) {
+    // forward-only callers (the U-Net): no score matrix at all -- flash_attn.hip walks the keys with an online softmax
+    act_t* vT = A.bf((size_t)Z * dh * Nkp);
+    if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
+    CRUN(dmx_transpose(v, vT, Nk, dh, C, Nkp, Z, heads, (long long)Nk * C, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
+    CRUN(dmx_flash_attn_fwd(q, k, vT, o, colbias, B, Nq, Nk, Nkp, C, heads, scale, cx.st));
+    A.release(mk);
+    return DMX_OK;
+  }
   act_t* Pm = P_keep ? P_keep : A.bf((size_t)Z * Nq * Nkp);
   act_t* vT = A.bf((size_t)Z * dh * Nkp);
   GemmBatch gb;

@@ -114,4 +114,12 @@ int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes,
   return dmx_conv_pair_launch(a, b, ST(stream));
 }
 
+int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, const float* colbias, int B, int Nq, int Nk, int Nkp, int C,
+                       int heads, float scale, void* stream) {
+  const int rc = dmx_flash_attn_fwd((const act_t*)q, (const act_t*)k, (const act_t*)vT, (act_t*)o, colbias, B, Nq, Nk, Nkp, C, heads, scale,
+                                    ST(stream));
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("flash attention: unsupported head_dim / strides");
+  return rc;
+}
+
 }  // extern "C"

@@ -1,0 +1,266 @@
+// Fused multi-head attention forward (no materialised score matrix) for the U-Net transformer blocks.
+//
+// The reference reaches this through diffusers' Attention processor inside UNet2DConditionModel
+// (diffmusic/pipelines/pipeline_musicldm.py:696-703 calls the U-Net twice per step on the CFG batch); the
+// U-Net is never differentiated on the hot path (scheduling_dps.py:195-212 differentiates the decoder
+// only), so a forward-only kernel is enough here.  The VAE mid-block attention needs its probabilities
+// for the backward pass and stays on the GEMM path (blocks.h attention_core with P_keep).
+//
+// o[b, i, h*dh:(h+1)*dh] = softmax_j(q_i . k_j * scale + colbias[b, j]) v_j
+//
+// One workgroup = 128 queries of one (batch, head); each of its 4 waves owns 32 queries.  Keys are walked in
+// blocks of 64.  Everything is computed transposed so that a lane owns ONE query column:
+//   S^T = K Q^T   (MFMA A = K fragment from LDS, B = Q fragment held in registers)
+//          -> lane (lr, lq) holds S^T[key 16t+4lq+e][query lr]: the row statistics of a query live in one lane
+//             (+ the three lanes lr+16, lr+32, lr+48: two xor-shuffles per block for the running maximum),
+//   O^T += V^T P^T (MFMA A = V^T fragment from LDS, B = the exponentiated accumulators re-used in place:
+//             the k slots of a 32-key MFMA step are defined as {16t0+4lq+j} u {16t1+4lq+j}, which is exactly what
+//             the S^T accumulators of two key tiles hold, so P never moves between lanes or through LDS).
+// exp2 with the scale folded into one FMA; running max / sum per lane (online softmax).  The loop is VALU-bound
+// (exp is quarter rate); the matrix work is 16 MFMAs per 64 keys at dh = 32.
+#include "dmx_common.h"
+#include "kernels.h"
+#include "conv_pair.h"
+
+namespace {
+
+constexpr int FA_KB = 64;     // keys per block
+constexpr int FA_QW = 32;     // queries per wave
+constexpr int FA_QB = 128;    // queries per workgroup
+
+template <int DK, int DT>     // DK: 32-wide k steps of q.k (dh <= 32*DK); DT: 16-wide tiles of the output dim (dh <= 16*DT)
+struct FaCfg {
+  static constexpr int KPITCH = DK * 64 + 32;          // bytes per key row of the K tile (+32: conflict-free ds_read_b128)
+  static constexpr int VPITCH = FA_KB * 2 + 16;        // bytes per d row of the V^T tile
+  static constexpr int KBYTES = FA_KB * KPITCH, VBYTES = DT * 16 * VPITCH;
+  static constexpr int KCH = FA_KB * DK * 4, VCH = DT * 16 * 8;      // 16-byte chunks per tile
+  static constexpr int KIT = (KCH + 255) / 256, VIT = (VCH + 255) / 256;
+  static constexpr int LDS = 2 * (KBYTES + VBYTES);
+};
+
+struct FaParams {
+  const act_t* q; const act_t* k; const act_t* vT; act_t* o;
+  const float* colbias;
+  int Nq, Nk, Nkp, C, heads, dh;
+  float c;                    // scale * log2(e)
+};
+
+template <int DK, int DT>
+__global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
+  using F = FaCfg<DK, DT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int z = blockIdx.y, b = z / P.heads, h = z - b * P.heads;
+  const int q0 = blockIdx.x * FA_QB + wave * FA_QW;
+  const int dh = P.dh, C = P.C, Nk = P.Nk;
+  const act_t* qb = P.q + (long long)b * P.Nq * C + h * dh;
+  const act_t* kb = P.k + (long long)b * Nk * C + h * dh;
+  const act_t* vb = P.vT + (long long)z * dh * P.Nkp;
+  const float NEG = -__builtin_huge_valf();
+
+  // ---- Q fragments (B operand): lane (lr, lq) holds q[query 16*qt + lr][32*ks + 8*lq .. +8]
+  frag8_t qf[2][DK];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int ks = 0; ks < DK; ++ks) {
+      const int qi = q0 + qt * 16 + lr, d = ks * 32 + lq * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (qi < P.Nq && d < dh) v = *reinterpret_cast<const uint4*>(qb + (long long)qi * C + d);
+      qf[qt][ks] = __builtin_bit_cast(frag8_t, v);
+    }
+
+  // ---- K / V^T tiles: global -> registers -> LDS, double buffered
+  uint4 kreg[F::KIT], vreg[F::VIT];
+  auto gload = [&](int blk) {
+    const int key0 = blk * FA_KB;
+#pragma unroll
+    for (int it = 0; it < F::KIT; ++it) {
+      const int c = tid + it * 256, row = c / (DK * 4), d = (c % (DK * 4)) * 8;
+      kreg[it] = make_uint4(0, 0, 0, 0);
+      if (c < F::KCH && key0 + row < Nk && d < dh) kreg[it] = *reinterpret_cast<const uint4*>(kb + (long long)(key0 + row) * C + d);
+    }
+#pragma unroll
+    for (int it = 0; it < F::VIT; ++it) {
+      const int c = tid + it * 256, row = c >> 3, key = key0 + (c & 7) * 8;
+      vreg[it] = make_uint4(0, 0, 0, 0);
+      if (c < F::VCH && row < dh && key < P.Nkp) vreg[it] = *reinterpret_cast<const uint4*>(vb + (long long)row * P.Nkp + key);
+    }
+  };
+  auto lstore = [&](int buf) {
+    char* kt = smem + buf * (F::KBYTES + F::VBYTES);
+    char* vt = kt + F::KBYTES;
+#pragma unroll
+    for (int it = 0; it < F::KIT; ++it) {
+      const int c = tid + it * 256;
+      if (c < F::KCH) *reinterpret_cast<uint4*>(kt + (c / (DK * 4)) * F::KPITCH + (c % (DK * 4)) * 16) = kreg[it];
+    }
+#pragma unroll
+    for (int it = 0; it < F::VIT; ++it) {
+      const int c = tid + it * 256;
+      if (c < F::VCH) *reinterpret_cast<uint4*>(vt + (c >> 3) * F::VPITCH + (c & 7) * 16) = vreg[it];
+    }
+  };
+
+  f32x4 oacc[DT][2];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {NEG, NEG}, l_run[2] = {0.f, 0.f};
+
+  const int nblk = (Nk + FA_KB - 1) / FA_KB;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int blk = 0; blk < nblk; ++blk) {
+    const int buf = blk & 1;
+    if (blk + 1 < nblk) gload(blk + 1);
+    const char* kt = smem + buf * (F::KBYTES + F::VBYTES);
+    const char* vt = kt + F::KBYTES;
+    // ---- S^T = K Q^T for 4 key tiles x 2 query tiles
+    f32x4 s[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      frag8_t kf[DK];
+#pragma unroll
+      for (int ks = 0; ks < DK; ++ks) kf[ks] = *reinterpret_cast<const frag8_t*>(kt + (t * 16 + lr) * F::KPITCH + ks * 64 + lq * 16);
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) a = DMX_MFMA16(kf[ks], qf[qt][ks], a);
+        s[t][qt] = a;
+      }
+    }
+    // ---- logits in the log2 domain, key mask / additive key bias
+    const int key0 = blk * FA_KB;
+    const float c = P.c;
+    const bool tail = key0 + FA_KB > Nk;
+    if (P.colbias || tail) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int kbase = key0 + t * 16 + lq * 4;
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (P.colbias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bb[e] = (kbase + e < Nk) ? P.colbias[(long long)b * Nk + kbase + e] * 1.4426950408889634f : 0.f;
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[t][qt][e] = (kbase + e < Nk) ? __builtin_fmaf(s[t][qt][e], c, bb[e]) : NEG;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[t][qt][e] *= c;
+    }
+    // ---- online softmax per query (= per lane column); the four lanes of a query share the maximum
+    frag8_t pf[2][2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = NEG;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][qt][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[qt], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);     // first block: exp2(-inf) = 0
+      m_run[qt] = m_new;
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f(s[t][qt][e] - m_new);
+          s[t][qt][e] = p;
+          sum += p;
+        }
+      l_run[qt] = l_run[qt] * alpha + sum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) oacc[dt][qt][e] *= alpha;
+      // P^T fragments: k slots (lq, j) of MFMA step kk <-> keys 32kk + {4lq + j, 16 + 4lq + j}
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const uint4 u = make_uint4(pack2a(s[2 * kk][qt][0], s[2 * kk][qt][1]), pack2a(s[2 * kk][qt][2], s[2 * kk][qt][3]),
+                                   pack2a(s[2 * kk + 1][qt][0], s[2 * kk + 1][qt][1]), pack2a(s[2 * kk + 1][qt][2], s[2 * kk + 1][qt][3]));
+        pf[qt][kk] = __builtin_bit_cast(frag8_t, u);
+      }
+    }
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const char* vrow = vt + (dt * 16 + lr) * F::VPITCH + (kk * 32 + lq * 4) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow), hi = *reinterpret_cast<const uint2*>(vrow + 32);
+        const frag8_t vf = __builtin_bit_cast(frag8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) oacc[dt][qt] = DMX_MFMA16(vf, pf[qt][kk], oacc[dt][qt]);
+      }
+    if (blk + 1 < nblk) lstore(buf ^ 1);     // the other buffer was last read before the previous barrier
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds o[query 16qt + lr][16dt + 4lq + e]
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    float l = l_run[qt];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    const int qi = q0 + qt * 16 + lr;
+    if (qi >= P.Nq) continue;
+    act_t* orow = P.o + ((long long)b * P.Nq + qi) * C + h * dh;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      const int d = dt * 16 + lq * 4;
+      if (d < dh)
+        *reinterpret_cast<uint2*>(orow + d) = make_uint2(pack2a(oacc[dt][qt][0] * inv, oacc[dt][qt][1] * inv),
+                                                         pack2a(oacc[dt][qt][2] * inv, oacc[dt][qt][3] * inv));
+    }
+  }
+}
+
+template <int DK, int DT>
+int launch_fa(const FaParams& P, int Z, hipStream_t st) {
+  using F = FaCfg<DK, DT>;
+  dim3 grid((unsigned)cdiv(P.Nq, FA_QB), (unsigned)Z, 1);
+  hipLaunchKernelGGL((flash_attn_fwd_kernel<DK, DT>), grid, dim3(256), F::LDS, st, P);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
+}  // namespace
+
+bool dmx_flash_attn_ok(int dh, int C, int Nkp) { return dh >= 8 && dh <= 96 && (dh & 3) == 0 && (dh & 7) == 0 && (C & 7) == 0 && (Nkp & 7) == 0; }
+
+// q (B, Nq, C), k (B, Nk, C) channels-last with `heads` heads of dh = C / heads; vT (B*heads, dh, Nkp) = per-head V^T with
+// zero columns in [Nk, Nkp); o (B, Nq, C).  colbias: optional additive key bias (B, Nk) fp32.
+int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* vT, act_t* o, const float* colbias, int B, int Nq, int Nk,
+                       int Nkp, int C, int heads, float scale, hipStream_t st) {
+  const int dh = C / heads;
+  if (!dmx_flash_attn_ok(dh, C, Nkp) || Nq < 1 || Nk < 1) return DMX_ERR_SHAPE;
+  FaParams P;
+  P.q = q; P.k = k; P.vT = vT; P.o = o; P.colbias = colbias;
+  P.Nq = Nq; P.Nk = Nk; P.Nkp = Nkp; P.C = C; P.heads = heads; P.dh = dh;
+  P.c = scale * 1.4426950408889634f;
+  const int Z = B * heads;
+  const int rec = dmx_prof_open(st);
+  int rc;
+  if (dh <= 32) rc = launch_fa<1, 2>(P, Z, st);
+  else if (dh <= 48) rc = launch_fa<2, 3>(P, Z, st);
+  else if (dh <= 64) rc = launch_fa<2, 4>(P, Z, st);
+  else if (dh <= 80) rc = launch_fa<3, 5>(P, Z, st);
+  else rc = launch_fa<3, 6>(P, Z, st);
+  dmx_prof_close(rec, st, 4.0 * Z * (double)Nq * Nk * dh, 2.0 * Z * (2.0 * Nq + 2.0 * Nk) * dh, Nq, Nk, dh, 1, 0, 30);
+  return rc;
+}
