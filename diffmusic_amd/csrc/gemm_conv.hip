@@ -179,7 +179,7 @@ constexpr unsigned NUMREC = OOB;
 #endif
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
+__device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 16, FN = TN / 16;
@@ -187,22 +187,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(A_ISS >= 1 && B_ISS >= 1, "tile too small");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   short2* s_taps = reinterpret_cast<short2*>(smem + NSTAGE * STAGE);
   constexpr int PER = A_ISS + B_ISS;              // LDS-DMA instructions per thread per stage
   constexpr int KEEP = (NSTAGE - 2) * PER;        // loads allowed in flight when the next tile must have landed
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int tiles_n = (p.N + BN - 1) / BN;
-  // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous run of logical tiles so the
-  // N-tiles of one M-tile and neighbouring M-tiles (shared A rows / halos, same weights) hit the same L2.  Bijective for any grid.
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
-  const int tn = bid % tiles_n, tm = bid / tiles_n;
   const int z = blockIdx.y;
   const int zo = z / p.Zi, zi = z - zo * p.Zi;
   const act_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
@@ -220,7 +210,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   int a_iy[A_ISS], a_ix[A_ISS];
 #pragma unroll
   for (int i = 0; i < A_ISS; ++i) {
-    const int m = tm * BM + (i * NW + wave) * 8 + lrow;
+    const int m = m0 + (i * NW + wave) * 8 + lrow;
     if (m < p.M) {
       const int b = m / HqWq, rem = m - b * HqWq;
       const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
@@ -394,13 +384,45 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   if (p.alpha == 12345.f)
 #endif
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
-    gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
+}
+
+// XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous run of logical tiles so the
+// N-tiles of one M-tile and neighbouring M-tiles (shared A rows / halos, same weights) hit the same L2.  Bijective for any grid.
+__device__ __forceinline__ int xcd_remap(int bid) {
+  const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x);
+  glds_tile<BM, BN, WM, WN, NSTAGE>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
+}
+
+// Two tile heights in one launch, alternating along M.  With uniform tiles every workgroup reaches its epilogue at the same
+// moment: HBM sits idle during the K loops and is the bottleneck during the simultaneous epilogue bursts (the store / residual
+// traffic of a 160 032 x 256 layer runs at ~3 TB/s for ~30 us per round while the matrix cores wait).  Tiles of BMA and BMB rows
+// take different times, so after the first tiles the workgroups drift apart and the epilogue traffic of some overlaps the K
+// loops of the others.
+template <int BMA, int BMB, int BN, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_mixed_kernel(const GemmDesc p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int bid = xcd_remap(blockIdx.x);
+  const int tmi = bid / tiles_n, tn = bid - tmi * tiles_n;
+  const int m0 = (tmi >> 1) * (BMA + BMB) + ((tmi & 1) ? BMA : 0);
+  if (m0 >= p.M) return;
+  if (tmi & 1) glds_tile<BMB, BN, WM, WN, NSTAGE>(p, smem, m0, tn);
+  else glds_tile<BMA, BN, WM, WN, NSTAGE>(p, smem, m0, tn);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
@@ -416,6 +438,23 @@ int launch_glds(const GemmDesc& d, hipStream_t stream) {
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
   hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
+template <int BMA, int BMB, int BN, int WM, int WN, int NSTAGE>
+int launch_glds_mixed(const GemmDesc& d, hipStream_t stream) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int BMX = BMA > BMB ? BMA : BMB;
+  constexpr int SMEM = NSTAGE * (BMX + BN) * 128 + DMX_MAX_TAPS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_mixed_kernel<BMA, BMB, BN, WM, WN, NSTAGE>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    attr_set = true;
+  }
+  const long long tiles = 2ll * cdiv(d.M, BMA + BMB) * cdiv(d.N, BN);
+  dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
+  hipLaunchKernelGGL((gemm_glds_mixed_kernel<BMA, BMB, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
@@ -472,6 +511,10 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 12: return launch_glds<64, 64, 2, 2, 4>(d, stream);
     case 13: return launch_glds<128, 64, 2, 2, 3>(d, stream);
     case 14: return launch_glds<64, 128, 2, 2, 3>(d, stream);
+    case 15: return launch_glds_mixed<320, 192, 256, 2, 4, 2>(d, stream);   // alternating tile heights: desynchronised epilogues
+    case 16: return launch_glds_mixed<320, 192, 128, 4, 2, 2>(d, stream);
+    case 17: return launch_glds_mixed<320, 256, 256, 2, 4, 2>(d, stream);
+    case 18: return launch_glds_mixed<256, 192, 256, 2, 4, 2>(d, stream);
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -481,7 +524,23 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 14 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
+    static int ovN[8], ovC[8], nov = -1;
+    if (nov < 0) {
+      nov = 0;
+      if (const char* e = getenv("DMX_CFG_OVERRIDE")) {
+        while (*e && nov < 8) {
+          int n = 0, c = 0;
+          if (sscanf(e, "%d:%d", &n, &c) == 2) { ovN[nov] = n; ovC[nov] = c; ++nov; }
+          while (*e && *e != ',') ++e;
+          if (*e == ',') ++e;
+        }
+      }
+    }
+    if (gl && d.M >= 40000)
+      for (int i = 0; i < nov; ++i) if (ovN[i] == d.N) return launch_by_cfg(ovC[i], d, stream);
+  }
   // measured best configuration for the shapes of the shipped benchmark configs (scripts/dev/tune_tiles.py)
   for (const TileEntry* e = g_tile_table; e->cfg; ++e)
     if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && ((e->cfg > 2 && e->cfg < 7) || gl)) return launch_by_cfg(e->cfg, d, stream);
@@ -546,7 +605,7 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
     if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
-    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 14);          // gemm_glds_kernel (LDS-DMA tiles)
+    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 18);          // gemm_glds_kernel (LDS-DMA tiles)
     if (dma) { g_dma_ms += t; g_dma_fl += r.flops; g_dma_by += r.bytes; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);

@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
-// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM)
+// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM)  (5-tile chunks for FM = 10 measured slower)
 template <int FM>
 struct EpiChunk { static constexpr int IB = (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 3 : (FM % 2 == 0) ? 2 : 1; static constexpr int CH = IB * 16; };
 
@@ -106,43 +106,61 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
   constexpr int PITCH = TNB + 16;
   constexpr int CPR = TNB / 16;           // 16-byte chunks per row
   constexpr int RPI = 64 / CPR;           // rows per wave-instruction in the row-major phase
+  constexpr int NIT = CH / RPI;           // wave-instructions per tensor and chunk
+  static_assert(CH % RPI == 0, "chunk rows must be a multiple of the rows per wave-instruction");
   const int lr = lane & 15, lq = lane >> 4;
   const int rr = lane / CPR, cch = lane - rr * CPR;
-  long long* tab = reinterpret_cast<long long*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range)
-  int* tabb = reinterpret_cast<int*>(wl + CH * PITCH + CH * 8);      // batch image per tile row
+  long long* tab = reinterpret_cast<long long*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range), general map only
   const int flags = p.flags;
   const int ncol = n0 + cch * 8;
   const bool col_ok = ncol < p.N;
+  const int mend = p.M < mlimit ? p.M : mlimit;
+  // stride-1 convolutions and plain GEMMs write GEMM row m to output row m: no index table, no divisions
+  const bool ident = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.Ho == p.Hq && p.Wo == p.Wq;
 #define DMX_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #pragma unroll
   for (int h = 0; h < FM / IB; ++h) {
-    if (lq == 0) {
+    // ---- output row of each tile row this lane touches in the row-major phases
+    long long orows[NIT];
+    if (ident) {
 #pragma unroll
-      for (int ii = 0; ii < IB; ++ii) {
-        const int m = m0 + (h * IB + ii) * 16 + lr;
+      for (int it = 0; it < NIT; ++it) {
+        const int m = m0 + h * CH + it * RPI + rr;
+        orows[it] = m < mend ? (long long)m : -1ll;
+      }
+    } else {
+      if (lane < CH) {
+        const int m = m0 + h * CH + lane;
         long long orow = -1;
-        int b = 0;
-        if (m < p.M && m < mlimit) {
-          b = m / HqWq;
-          const int rem = m - b * HqWq;
+        if (m < mend) {
+          const int b = m / HqWq, rem = m - b * HqWq;
           const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
           orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
         }
-        tab[ii * 16 + lr] = orow;
-        tabb[ii * 16 + lr] = b;
+        tab[lane] = orow;
       }
-    }
-    DMX_LDS_SYNC();
-    // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`
-    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
+      DMX_LDS_SYNC();
 #pragma unroll
-      for (int r0 = 0; r0 < CH; r0 += RPI) {
-        const int row = r0 + rr;
-        const long long orow = tab[row];
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (orow >= 0 && col_ok) v = *reinterpret_cast<const uint4*>(G + coff + orow * ld + ncol);
-        *reinterpret_cast<uint4*>(wl + row * PITCH + cch * 16) = v;
+      for (int it = 0; it < NIT; ++it) orows[it] = tab[it * RPI + rr];
+      DMX_LDS_SYNC();
+    }
+    // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`.  All loads of a chunk are issued back to
+    // back from always-valid addresses (out-of-range rows read element 0 and are zeroed): one exposed latency per tensor.
+    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
+      uint4 v[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const bool ok = orows[it] >= 0 && col_ok;
+        const long long off = ok ? orows[it] * ld + ncol : 0ll;
+#ifndef DMX_EPI_NOLOAD
+        v[it] = *reinterpret_cast<const uint4*>(G + coff + off);
+#else
+        v[it] = make_uint4(0, 0, 0, 0);
+#endif
+        if (!ok) v[it] = make_uint4(0, 0, 0, 0);
       }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = v[it];
       DMX_LDS_SYNC();
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
@@ -163,14 +181,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
           *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
         }
       DMX_LDS_SYNC();
+      uint4 v[NIT];
 #pragma unroll
-      for (int r0 = 0; r0 < CH; r0 += RPI) {
-        const int row = r0 + rr;
-        const long long orow = tab[row];
-        const uint4 v = *reinterpret_cast<const uint4*>(wl + row * PITCH + cch * 16);
-        if (orow >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + orow * ld + ncol) = v;
-      }
+      for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
       DMX_LDS_SYNC();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+#ifndef DMX_EPI_NOSTORE
+        if (orows[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + orows[it] * ld + ncol) = v[it];
+#else
+        if (orows[it] == -12345 && col_ok) *reinterpret_cast<uint4*>(G + coff + orows[it] * ld + ncol) = v[it];
+#endif
+      }
     };
     if (flags & EPI_MASK) {
       const float sl = p.mask_slope;
@@ -180,7 +202,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
     }
     if (flags & (EPI_BIAS | EPI_ROWBIAS)) {
 #pragma unroll
-      for (int ii = 0; ii < IB; ++ii)
+      for (int ii = 0; ii < IB; ++ii) {
+        int bimg = 0;
+        if (flags & EPI_ROWBIAS) {
+          const int m = m0 + h * CH + ii * 16 + lr;
+          bimg = (m < p.M ? m : 0) / HqWq;
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int n = n0 + j * 16 + lq * 4;
@@ -191,10 +218,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
           if (flags & EPI_ROWBIAS) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)tabb[ii * 16 + lr] * p.N + n);
+            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)bimg * p.N + n);
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
         }
+      }
     }
     if (flags & EPI_RESID) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
@@ -217,14 +245,17 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
     }
-    if (!(flags & EPI_NO_C))
+    if (!(flags & EPI_NO_C)) {
       stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+      DMX_LDS_SYNC();
+    }
     if (flags & EPI_LRELU2) {
       const float sl = p.act_slope;
       stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
         o[0] = a[0] > 0.f ? a[0] : a[0] * sl; o[1] = a[1] > 0.f ? a[1] : a[1] * sl;
         o[2] = a[2] > 0.f ? a[2] : a[2] * sl; o[3] = a[3] > 0.f ? a[3] : a[3] * sl;
       });
+      DMX_LDS_SYNC();
     }
   }
 #undef DMX_LDS_SYNC

@@ -24,8 +24,9 @@ struct HifiGan : Model {
   std::vector<act_t*> act_out;        // [stage] lrelu(stage output) (slope of the consumer)
   float* wav8 = nullptr;               // (B, Tout, 8) fp32 tanh output, channel 0 real
   bool have_tape = false;
-  // The nk resblock branches of a stage are independent until their outputs are averaged: they run on their own HIP
-  // streams so that the tail of one branch's launches (314 tiles on 256 CUs at M = 40 008) is filled by the others.
+  // The nk resblock branches of a stage are independent until their outputs are averaged: optionally (DMX_MULTI_STREAM=1) they
+  // run on their own HIP streams so that the tail of one branch's launches is filled by the others.  Off by default: with the
+  // round-filling tile heights and the fused pair kernel the tails are short and one stream measures faster.
   hipStream_t bstream[DMX_MAX_STAGES] = {};
   std::vector<hipEvent_t> events;
   size_t ev_next = 0;
@@ -58,7 +59,9 @@ struct HifiGan : Model {
       }
     }
     conv_post = make_conv1d(ps, "conv_post", ch, 1, 7, 1, 3, true);
-    want_multi = getenv("DMX_SINGLE_STREAM") == nullptr;
+    // measured after the fused resblock-pair kernel: one stream is ~0.9 ms/step faster than three (the tails the extra streams
+    // used to fill are gone); DMX_MULTI_STREAM=1 restores the three-stream schedule
+    want_multi = getenv("DMX_MULTI_STREAM") != nullptr && getenv("DMX_SINGLE_STREAM") == nullptr;
     for (int k = 1; k < nk; ++k) (void)hipStreamCreateWithFlags(&bstream[k], hipStreamNonBlocking);
     events.resize(256);
     for (auto& e : events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);

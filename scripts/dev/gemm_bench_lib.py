@@ -12,13 +12,13 @@ def desc(**kw):
         else: setattr(d, k, v)
     return d
 
-def bench(name, B, T, Ci, Co, k, dil=1, reps=20, flags=0):
+def bench(name, B, T, Ci, Co, k, dil=1, reps=20, flags=0, cfg=0):
     x = torch.randn(B, T, Ci, device="cuda").half(); w = (torch.randn(Co, k * Ci, device="cuda") / (k * Ci) ** 0.5).half()
     out = torch.empty(B, T, Co, device="cuda", dtype=torch.float16); res = torch.randn(B, T, Co, device="cuda").half(); out2 = torch.empty_like(out)
     bias = torch.randn(Co, device="cuda")
     pad = (k * dil - dil) // 2
     d = desc(A=x, W=w, C=out, C2=out2, R=res, bias=bias, M=B * T, N=Co, K=k * Ci, ldw=k * Ci, Hi=1, Wi=T, Ci=Ci, lda=Ci, Hq=1, Wq=T, ntaps=k,
-             Ho=1, Wo=T, ldc=Co, ldr=Co, ldx=Co, ldc2=Co, flags=flags, act_slope=0.1, tdy=[0] * k, tdx=[t * dil - pad for t in range(k)])
+             Ho=1, Wo=T, ldc=Co, ldr=Co, ldx=Co, ldc2=Co, flags=flags, act_slope=0.1, tdy=[0] * k, tdx=[t * dil - pad for t in range(k)], tile_cfg=cfg)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     f = lambda: L.check(L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), st), "gemm")
     for _ in range(3): f()

@@ -1,0 +1,6 @@
+#!/bin/bash
+for v in "$@"; do
+  echo "=== variant: [$v]"
+  DMX_EXTRA_FLAGS="$v" python -m diffmusic_amd.build --force > gpurun_out/build.log 2>&1 || { echo build failed; grep -m3 error -A5 gpurun_out/build.log; continue; }
+  timeout -k 10 200 python scripts/dev/gemm_set.py 2>&1 | grep TF/s
+done
