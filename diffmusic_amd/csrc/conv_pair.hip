@@ -318,6 +318,8 @@ bool dmx_conv_pair_eligible(const GemmDesc* a, const GemmDesc& b) {
   if (T < 1) return false;
   const int bflags = EPI_BIAS | EPI_RESID | EPI_RESID_INV | EPI_ACCUM | EPI_MASK | EPI_LRELU2 | EPI_NO_C;
   if (!stage_ok(b, C, T, bflags) || !halo_of(b).ok) return false;
+  if ((b.flags & EPI_LRELU2) && !(b.act_slope >= 0.f && b.act_slope <= 1.f)) return false;
+  if ((b.flags & EPI_RESID_INV) && !(b.resid_inv_slope >= 1.f)) return false;
   if (b.ldc != C || ((b.flags & EPI_RESID) && b.ldr != C) || ((b.flags & EPI_MASK) && b.ldx != C) || ((b.flags & EPI_LRELU2) && b.ldc2 != C))
     return false;
   if (a) {

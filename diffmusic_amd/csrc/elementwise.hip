@@ -108,44 +108,63 @@ __global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __re
   }
 }
 
-// combine partials -> stats[b,g] = (mean, rstd); scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma.
-// 8 lanes per group walk the chunk partials in parallel (two passes: weighted mean, then M2 about it).
-__device__ __forceinline__ float sum8(float v) {
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-  return v;
+// Block-wide reduction over the k index of values laid out (k, g): thread t holds g = t % G.  Lanes t and t + 32 of a wave
+// share g when G == 32; waves are combined through `sh` (blockDim/64 x G floats).  Returns the total for group t % G to every thread.
+__device__ __forceinline__ float gn_group_total(float v, float* sh, int G) {
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nw = blockDim.x >> 6;
+  if (G <= 32) {
+    for (int o = 32; o >= G; o >>= 1) v += __shfl_xor(v, o, 64);
+  }
+  __syncthreads();
+  if (lane < G || G > 32) sh[w * 64 + lane] = v;
+  __syncthreads();
+  float r = 0.f;
+  const int g = tid % G;
+  if (G <= 32) { for (int i = 0; i < nw; ++i) r += sh[i * 64 + g]; }
+  else { for (int i = 0; i < nw; ++i) r += sh[i * 64 + (lane % G)]; }
+  return r;
 }
-__global__ __launch_bounds__(512) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
+
+// combine partials -> stats[b,g] = (mean, rstd); scale[b,c] = rstd*gamma, shift[b,c] = beta - mean*rstd*gamma.
+// One 1024-thread block per image; thread t owns group t % G and chunks t / G, t / G + 1024 / G, ...: every pass over the
+// partials is one fully coalesced sweep with all loads in flight at once (the old 8-lanes-per-group walk exposed ~64
+// dependent cache-line latencies per launch: 16 us for a kernel that moves 128 KB).
+constexpr int GN_FIN_MAXIT = 32;
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ stats,
                                    float* __restrict__ scale, float* __restrict__ shift,
                                    int P, int C, int G, int nchunk, int ppb, float eps) {
+  __shared__ float sh[16 * 64];
   __shared__ float s_mean[64], s_rstd[64];
   const int b = blockIdx.x, cpg = C / G;
-  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  if (g < G) {
-    float sw = 0.f, sn = 0.f;
-    for (int k = sub; k < nchunk; k += 8) {
-      const int cnt = min(P, (k + 1) * ppb) - k * ppb;
-      const float nb = (float)cnt * cpg;
-      sw += nb * partial[(((long long)b * nchunk + k) * G + g) * 2];
-      sn += nb;
+  const int g = threadIdx.x % G, kk = threadIdx.x / G, kstep = blockDim.x / G;
+  float2 pv[GN_FIN_MAXIT];
+  float nbv[GN_FIN_MAXIT];
+#pragma unroll
+  for (int it = 0; it < GN_FIN_MAXIT; ++it) {
+    const int k = kk + it * kstep;
+    pv[it] = make_float2(0.f, 0.f);
+    nbv[it] = 0.f;
+    if (k < nchunk) {
+      pv[it] = *reinterpret_cast<const float2*>(partial + (((long long)b * nchunk + k) * G + g) * 2);
+      nbv[it] = (float)(min(P, (k + 1) * ppb) - k * ppb) * cpg;
     }
-    sw = sum8(sw); sn = sum8(sn);
-    const float mean = sw / sn;
-    float m2 = 0.f;
-    for (int k = sub; k < nchunk; k += 8) {
-      const int cnt = min(P, (k + 1) * ppb) - k * ppb;
-      const float nb = (float)cnt * cpg;
-      const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
-      const float d = pp[0] - mean;
-      m2 += pp[1] + nb * d * d;
-    }
-    m2 = sum8(m2);
-    if (sub == 0) {
-      const float rstd = rsqrtf(m2 / sn + eps);
-      s_mean[g] = mean; s_rstd[g] = rstd;
-      stats[((long long)b * G + g) * 2] = mean;
-      stats[((long long)b * G + g) * 2 + 1] = rstd;
-    }
+  }
+  float sw = 0.f, sn = 0.f;
+#pragma unroll
+  for (int it = 0; it < GN_FIN_MAXIT; ++it) { sw += nbv[it] * pv[it].x; sn += nbv[it]; }
+  sw = gn_group_total(sw, sh, G);
+  sn = gn_group_total(sn, sh, G);
+  const float mean = sw / sn;
+  float m2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < GN_FIN_MAXIT; ++it) { const float d = pv[it].x - mean; m2 += pv[it].y + nbv[it] * d * d; }
+  m2 = gn_group_total(m2, sh, G);
+  if (threadIdx.x < G) {
+    const float rstd = rsqrtf(m2 / sn + eps);
+    s_mean[g] = mean; s_rstd[g] = rstd;
+    stats[((long long)b * G + g) * 2] = mean;
+    stats[((long long)b * G + g) * 2 + 1] = rstd;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -190,24 +209,28 @@ __global__ void gn_apply_kernel(const act_t* __restrict__ x, const float* __rest
 }
 
 // backward finalize: per (b,c) coefficients k0, k1 with dx = scale*dy*act'(z) + k0 + k1*x
-__global__ __launch_bounds__(512) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
+__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
                                        float* __restrict__ k0, float* __restrict__ k1,
                                        int P, int C, int G, int nchunk) {
+  __shared__ float sh[16 * 64];
   __shared__ float s_c1[64], s_c2[64];
   const int b = blockIdx.x, cpg = C / G;
-  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  if (g < G) {
-    float a = 0.f, q = 0.f;
-    for (int k = sub; k < nchunk; k += 8) {
-      const float* pp = partial + (((long long)b * nchunk + k) * G + g) * 2;
-      a += pp[0]; q += pp[1];
+  const int g = threadIdx.x % G, kk = threadIdx.x / G, kstep = blockDim.x / G;
+  float a = 0.f, q = 0.f;
+#pragma unroll
+  for (int it = 0; it < GN_FIN_MAXIT; ++it) {
+    const int k = kk + it * kstep;
+    if (k < nchunk) {
+      const float2 pp = *reinterpret_cast<const float2*>(partial + (((long long)b * nchunk + k) * G + g) * 2);
+      a += pp.x; q += pp.y;
     }
-    a = sum8(a); q = sum8(q);
-    if (sub == 0) {
-      const float n = (float)P * cpg;
-      s_c1[g] = a / n;   // mean(dz*gamma*rstd)          (rstd already folded in via `scale`)
-      s_c2[g] = q / n;   // mean(dz*gamma*rstd * xhat)
-    }
+  }
+  a = gn_group_total(a, sh, G);
+  q = gn_group_total(q, sh, G);
+  if (threadIdx.x < G) {
+    const float n = (float)P * cpg;
+    s_c1[g] = a / n;   // mean(dz*gamma*rstd)          (rstd already folded in via `scale`)
+    s_c2[g] = q / n;   // mean(dz*gamma*rstd * xhat)
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -603,13 +626,13 @@ size_t dmx_gn_scratch_floats(int B, int C, int G) {
 
 int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, float* stats, float* scale,
                       float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st) {
-  if ((C & 7) || C % G || G > 64 || C > 2048) return DMX_ERR_SHAPE;
+  if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
   int nt, rpb, nchunk, ppb;
   gn_geom(P, C, nt, rpb, nchunk, ppb);
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
                      (const act_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial,
                      P, C, G, rpb, ppb, 0);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(512), 0, st, partial, gamma, beta, stats, scale, shift, P, C, G,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, st, partial, gamma, beta, stats, scale, shift, P, C, G,
                      nchunk, ppb, eps);
   if (y) hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, scale, shift, y, P, C, rpb, ppb, silu);
   return CHECK_LAUNCH();
@@ -618,12 +641,12 @@ int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
 int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* dx, const float* stats,
                       const float* scale, const float* shift, float* k0, float* k1, float* partial, int B, int P, int C,
                       int G, int silu, hipStream_t st) {
-  if ((C & 7) || C % G || G > 64 || C > 2048) return DMX_ERR_SHAPE;
+  if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
   int nt, rpb, nchunk, ppb;
   gn_geom(P, C, nt, rpb, nchunk, ppb);
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x, dy,
                      scale, shift, stats, partial, P, C, G, rpb, ppb, silu);
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(512), 0, st, partial, stats, k0, k1, P, C, G, nchunk);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(1024), 0, st, partial, stats, k0, k1, P, C, G, nchunk);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, dy, scale, shift, k0, k1, add, dx, P, C,
                      rpb, ppb, silu);
   return CHECK_LAUNCH();

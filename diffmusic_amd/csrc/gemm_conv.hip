@@ -639,6 +639,9 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   if ((d.Ci & 7) || (d.N & 3) || (d.K & 7) || (d.lda & 7) || (d.ldw & 7) || (d.ldc & 3)) return DMX_ERR_SHAPE;
   if (d.ntaps < 1 || d.ntaps > DMX_MAX_TAPS || d.K != d.ntaps * d.Ci) return DMX_ERR_SHAPE;
   if (d.Z < 1 || d.Zi < 1) return DMX_ERR_SHAPE;
+  // the LDS epilogue evaluates leaky-relu as max(v, v*slope) and the inverse as min(x, x/slope)
+  if ((d.flags & EPI_LRELU2) && !(d.act_slope >= 0.f && d.act_slope <= 1.f)) return DMX_ERR_SHAPE;
+  if ((d.flags & EPI_RESID_INV) && !(d.resid_inv_slope >= 1.f)) return DMX_ERR_SHAPE;
   if (!g_prof) return launch_dispatch(d, stream);
   ProfRec r;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);

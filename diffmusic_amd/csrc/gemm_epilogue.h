@@ -227,10 +227,11 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
     if (flags & EPI_RESID) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
       stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
-        a[0] += x0 > 0.f ? x0 : x0 * is; a[1] += x1 > 0.f ? x1 : x1 * is; a[2] += x2 > 0.f ? x2 : x2 * is; a[3] += x3 > 0.f ? x3 : x3 * is;
+        // x > 0 ? x : x * is  ==  min(x, x * is) for is >= 1 (is = 1 / leaky slope, or exactly 1 for a plain residual)
+        a[0] += fminf(x0, x0 * is); a[1] += fminf(x1, x1 * is); a[2] += fminf(x2, x2 * is); a[3] += fminf(x3, x3 * is);
       });
     }
-    {
+    if (p.alpha != 1.f) {
       const float al = p.alpha;
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
@@ -252,8 +253,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
     if (flags & EPI_LRELU2) {
       const float sl = p.act_slope;
       stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
-        o[0] = a[0] > 0.f ? a[0] : a[0] * sl; o[1] = a[1] > 0.f ? a[1] : a[1] * sl;
-        o[2] = a[2] > 0.f ? a[2] : a[2] * sl; o[3] = a[3] > 0.f ? a[3] : a[3] * sl;
+        // leaky-relu with 0 <= slope <= 1 (checked at launch): max(v, v * slope)
+        o[0] = fmaxf(a[0], a[0] * sl); o[1] = fmaxf(a[1], a[1] * sl); o[2] = fmaxf(a[2], a[2] * sl); o[3] = fmaxf(a[3], a[3] * sl);
       });
       DMX_LDS_SYNC();
     }
