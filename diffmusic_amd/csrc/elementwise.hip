@@ -3,6 +3,7 @@
 // the layout conversions at the stage boundaries.  Activations are channels-last bf16; every
 // thread moves 16 bytes (8 channels) per access and reductions use wave64 shuffles + LDS.
 #include "dmx_common.h"
+#include <cstdlib>
 #include "kernels.h"
 
 namespace {
@@ -605,6 +606,68 @@ __global__ void pad_col8_act_kernel(const act_t* __restrict__ v, act_t* __restri
   reinterpret_cast<uint4*>(y)[idx] = make_uint4((uint32_t)v[idx], 0u, 0u, 0u);
 }
 
+// Single-launch GroupNorm (+SiLU) for small images (the U-Net levels: 64 .. 1000 pixels): one workgroup per (group, image)
+// keeps its P x C/G slice in registers, two-pass mean / variance, normalises and writes.  Replaces three launches
+// (partial, finalize, apply) whose cost at these sizes is launch latency, not bytes.
+constexpr int GN_SMALL_MAXU = 16;      // 4-channel units per thread
+__global__ __launch_bounds__(256) void gn_small_kernel(const act_t* __restrict__ x, act_t* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ stats, float* __restrict__ scale, float* __restrict__ shift,
+                                                       int P, int C, int G, float eps, int silu) {
+  __shared__ float sh[16];
+  const int g = blockIdx.x, b = blockIdx.y, cpg = C / G, U = cpg >> 2, c0 = g * cpg;
+  const int units = P * U;
+  const act_t* xb = x + (long long)b * P * C + c0;
+  uint2 v[GN_SMALL_MAXU];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN_SMALL_MAXU; ++i) {
+    const int u = threadIdx.x + i * 256;
+    v[i] = make_uint2(0, 0);
+    if (u < units) {
+      const int px = u / U, cu = u - px * U;
+      v[i] = *reinterpret_cast<const uint2*>(xb + (long long)px * C + cu * 4);
+      sum += alo(v[i].x) + ahi(v[i].x) + alo(v[i].y) + ahi(v[i].y);
+    }
+  }
+  const float n = (float)units * 4.f;
+  const float mean = block_sum(sum, sh) / n;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < GN_SMALL_MAXU; ++i) {
+    if (threadIdx.x + i * 256 < units) {
+      const float d0 = alo(v[i].x) - mean, d1 = ahi(v[i].x) - mean, d2 = alo(v[i].y) - mean, d3 = ahi(v[i].y) - mean;
+      m2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(m2, sh) / n + eps);
+  if (threadIdx.x == 0) {
+    stats[((long long)b * G + g) * 2] = mean;
+    stats[((long long)b * G + g) * 2 + 1] = rstd;
+  }
+  if (threadIdx.x < cpg) {
+    const int c = c0 + threadIdx.x;
+    const float a = rstd * gamma[c];
+    scale[(long long)b * C + c] = a;
+    shift[(long long)b * C + c] = beta[c] - mean * a;
+  }
+  if (!y) return;
+  act_t* yb = y + (long long)b * P * C + c0;
+#pragma unroll
+  for (int i = 0; i < GN_SMALL_MAXU; ++i) {
+    const int u = threadIdx.x + i * 256;
+    if (u < units) {
+      const int px = u / U, cu = u - px * U;
+      const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + cu * 4);
+      const float4 be = *reinterpret_cast<const float4*>(beta + c0 + cu * 4);
+      float z0 = (alo(v[i].x) - mean) * rstd * ga.x + be.x, z1 = (ahi(v[i].x) - mean) * rstd * ga.y + be.y;
+      float z2 = (alo(v[i].y) - mean) * rstd * ga.z + be.z, z3 = (ahi(v[i].y) - mean) * rstd * ga.w + be.w;
+      if (silu) { z0 = silu_f(z0); z1 = silu_f(z1); z2 = silu_f(z2); z3 = silu_f(z3); }
+      *reinterpret_cast<uint2*>(yb + (long long)px * C + cu * 4) = make_uint2(pack2a(z0, z1), pack2a(z2, z3));
+    }
+  }
+}
+
 inline void gn_geom(int P, int C, int& nt, int& rpb, int& nchunk, int& ppb) {
   const int cpr = C >> 3;
   rpb = cpr >= 256 ? 1 : 256 / cpr;
@@ -627,6 +690,12 @@ size_t dmx_gn_scratch_floats(int B, int C, int G) {
 int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, float* stats, float* scale,
                       float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st) {
   if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
+  const int cpg = C / G;
+  static const bool small_ok = getenv("DMX_NO_GN_SMALL") == nullptr;
+  if (small_ok && (cpg & 3) == 0 && cpg <= 256 && (long long)P * (cpg >> 2) <= 256ll * GN_SMALL_MAXU && (long long)B * G >= 128) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, st, x, y, gamma, beta, stats, scale, shift, P, C, G, eps, silu);
+    return CHECK_LAUNCH();
+  }
   int nt, rpb, nchunk, ppb;
   gn_geom(P, C, nt, rpb, nchunk, ppb);
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
