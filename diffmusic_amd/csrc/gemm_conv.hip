@@ -605,7 +605,7 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
     if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
-    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 18);          // gemm_glds_kernel (LDS-DMA tiles)
+    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10) || (r.cfg >= 15 && r.cfg <= 18);   // gemm_glds_kernel, 8-wave tiles (256/320/192 rows)
     if (dma) { g_dma_ms += t; g_dma_fl += r.flops; g_dma_by += r.bytes; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
