@@ -86,3 +86,17 @@ def test_audioldm2_dsg_phase_retrieval_runs():
                generator=gens, measurement=y, eta=1.0, ip_guidance_rate=0.08, show_progress=False)
     assert out.audios.shape == (B, L) and bool(torch.isfinite(torch.from_numpy(out.audios)).all())
     assert len(pipe.last_losses) == 4 and all(bool(torch.isfinite(l).all()) for l in pipe.last_losses)
+
+
+def test_example_driver_end_to_end(tmp_path):
+    """examples/run_inverse_problem.py: run.py-style wiring, three guided steps, wav / mel outputs and metrics."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("run_inverse_problem", os.path.join(os.path.dirname(__file__), "..", "examples",
+                                                                                      "run_inverse_problem.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main(["-c", "dps", "-t", "music_inpainting", "--batch", "2", "--num_inference_steps", "3", "--output_dir", str(tmp_path)])
+    out = tmp_path / "musicldm" / "moises" / "dps" / "music_inpainting"
+    for d in ("wav_input", "wav_recon", "wav_label", "mel_recon"):
+        assert len(list((out / d).iterdir())) == 2

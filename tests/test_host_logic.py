@@ -77,3 +77,29 @@ def test_mask_generation_matches_golden(golden_dir):
     torch.manual_seed(1234)
     op.mask_type, op.mask_duration_s = "random", 0.5
     assert np.array_equal(np.nonzero(gm(op)[0].numpy() == 0)[0], fx["mask_random_seed1234/zeros"])
+
+
+def _load_driver():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("run_inverse_problem", os.path.join(os.path.dirname(__file__), "..", "examples",
+                                                                                      "run_inverse_problem.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_example_driver_host_side():
+    """examples/run_inverse_problem.py: argument parsing and clip loading (operators need the GPU)."""
+    import numpy as np
+    import scipy.io.wavfile
+    import tempfile, os
+    mod = _load_driver()
+    args = mod.parse_args(["-c", "mpgd", "-t", "super_resolution", "--batch", "2"])
+    assert args.config_name == "mpgd" and args.batch == 2 and args.weights == "synthetic"
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "a.wav")
+        scipy.io.wavfile.write(path, 16000, (np.sin(np.arange(4000) / 10.0) * 20000).astype(np.int16))
+        clips = mod.load_clips([path], 2, 16000, 8000, 0)
+    assert clips.shape == (2, 8000) and float(clips.abs().max()) <= 1.0
+    assert float(clips[0, 4000:].abs().max()) == 0.0            # short file zero-padded to the clip length
