@@ -184,7 +184,9 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
       uint4 v[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
-      DMX_LDS_SYNC();
+      // (no explicit wait here: the stores depend on v through registers, and a later LDS write of this wave cannot pass
+      //  these reads -- LDS operations of one wave complete in order.  A "memory"-clobbering asm at this point made hipcc
+      //  keep v[] in scratch: every output byte was written twice.)
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
 #ifndef DMX_EPI_NOSTORE
