@@ -124,7 +124,7 @@ def cpu_baseline(seed_sd, threads):
 
 
 def pmc_traffic(prefix):
-    """HBM-side bytes per launch of one kernel family from the committed counter passes
+    """HBM-side bytes per launch of one kernel family (its 8-wave tiles, >= 192 rows) from the committed counter passes
     (profiles/r01_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate `rocprofv3 --pmc` runs of this same command,
     KiB -> bytes, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be read from inside the process."""
     import csv
@@ -133,7 +133,7 @@ def pmc_traffic(prefix):
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             with open(os.path.join(here, "profiles", f"r01_pmc_{c}_per_kernel.csv")) as fh:
-                rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(prefix)]
+                rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(prefix + "<") and int(r["kernel"].split("<")[1].split(",")[0]) >= 192]
             tot += sum(float(r[f"{c}_bytes_total"]) for r in rows)
             n = sum(int(r["launches"]) for r in rows)
     except (OSError, KeyError):
