@@ -132,7 +132,10 @@ struct Resnet2D {
 // o = softmax(q k^T * scale [+ colbias]) v, all through batched NT GEMMs with materialised scores.
 // P_keep (B*heads, Nq, Nk) fp16 is written to caller memory when backward needs it, else a temp.
 inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* v, act_t* o, int B, int Nq, int Nk, int C,
-                          int heads, act_t* P_keep, const float* colbias) {
+                          int heads, act_t* P_keep, const float* colbias, int ldq = 0, int ldk = 0, int ldv = 0) {
+  if (ldq <= 0) ldq = C;     // row strides of q / k / v (3C when they are slices of one fused QKV projection)
+  if (ldk <= 0) ldk = C;
+  if (ldv <= 0) ldv = C;
   Arena& A = *cx.arena;
   const int dh = C / heads, Z = B * heads;
   const int Nkp = pad8(Nk);           // P / vT rows are padded to a multiple of 8 keys (zero columns)
@@ -146,8 +149,8 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
     // forward-only callers (the U-Net): no score matrix at all -- flash_attn.hip walks the keys with an online softmax
     act_t* vT = A.bf((size_t)Z * dh * Nkp);
     if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
-    CRUN(dmx_transpose(v, vT, Nk, dh, C, Nkp, Z, heads, (long long)Nk * C, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
-    CRUN(dmx_flash_attn_fwd(q, k, vT, o, colbias, B, Nq, Nk, Nkp, C, heads, scale, cx.st));
+    CRUN(dmx_transpose(v, vT, Nk, dh, ldv, Nkp, Z, heads, (long long)Nk * ldv, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
+    CRUN(dmx_flash_attn_fwd(q, k, vT, o, colbias, B, Nq, Nk, Nkp, C, heads, scale, cx.st, ldq, ldk));
     A.release(mk);
     return DMX_OK;
   }
@@ -155,15 +158,15 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
   act_t* vT = A.bf((size_t)Z * dh * Nkp);
   GemmBatch gb;
   gb.Z = Z; gb.Zi = heads;
-  gb.sAo = (long long)Nq * C; gb.sAi = dh;
-  gb.sBo = (long long)Nk * C; gb.sBi = dh;
+  gb.sAo = (long long)Nq * ldq; gb.sAi = dh;
+  gb.sBo = (long long)Nk * ldk; gb.sBi = dh;
   gb.sCo = (long long)heads * Nq * Nkp; gb.sCi = (long long)Nq * Nkp;
   Epi e; e.alpha = scale;
-  CRUN(gemm_nt(q, C, k, C, Pm, Nkp, Nq, Nk, dh, e, gb, cx.st));
+  CRUN(gemm_nt(q, ldq, k, ldk, Pm, Nkp, Nq, Nk, dh, e, gb, cx.st));
   CRUN(dmx_softmax_act(Pm, Pm, colbias, (long long)Z * Nq, Nk, Nkp, heads * Nq, cx.st));
   if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
   // vT[z] (dh, Nkp) = v[b, :, h*dh:(h+1)*dh]^T
-  CRUN(dmx_transpose(v, vT, Nk, dh, C, Nkp, Z, heads, (long long)Nk * C, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
+  CRUN(dmx_transpose(v, vT, Nk, dh, ldv, Nkp, Z, heads, (long long)Nk * ldv, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
   GemmBatch g2;
   g2.Z = Z; g2.Zi = heads;
   g2.sAo = (long long)heads * Nq * Nkp; g2.sAi = (long long)Nq * Nkp;

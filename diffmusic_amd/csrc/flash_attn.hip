@@ -41,7 +41,7 @@ struct FaCfg {
 struct FaParams {
   const act_t* q; const act_t* k; const act_t* vT; act_t* o;
   const float* colbias;
-  int Nq, Nk, Nkp, C, heads, dh;
+  int Nq, Nk, Nkp, C, heads, dh, ldq, ldk;      // C = row stride of o; ldq / ldk = row strides of q / k (a fused QKV buffer has 3C)
   float c;                    // scale * log2(e)
 };
 
@@ -54,8 +54,9 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
   const int z = blockIdx.y, b = z / P.heads, h = z - b * P.heads;
   const int q0 = blockIdx.x * FA_QB + wave * FA_QW;
   const int dh = P.dh, C = P.C, Nk = P.Nk;
-  const act_t* qb = P.q + (long long)b * P.Nq * C + h * dh;
-  const act_t* kb = P.k + (long long)b * Nk * C + h * dh;
+  const int ldq = P.ldq, ldk = P.ldk;
+  const act_t* qb = P.q + (long long)b * P.Nq * ldq + h * dh;
+  const act_t* kb = P.k + (long long)b * Nk * ldk + h * dh;
   const act_t* vb = P.vT + (long long)z * dh * P.Nkp;
   const float NEG = -__builtin_huge_valf();
 
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
     for (int ks = 0; ks < DK; ++ks) {
       const int qi = q0 + qt * 16 + lr, d = ks * 32 + lq * 8;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (qi < P.Nq && d < dh) v = *reinterpret_cast<const uint4*>(qb + (long long)qi * C + d);
+      if (qi < P.Nq && d < dh) v = *reinterpret_cast<const uint4*>(qb + (long long)qi * ldq + d);
       qf[qt][ks] = __builtin_bit_cast(frag8_t, v);
     }
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
     for (int it = 0; it < F::KIT; ++it) {
       const int c = tid + it * 256, row = c / (DK * 4), d = (c % (DK * 4)) * 8;
       kreg[it] = make_uint4(0, 0, 0, 0);
-      if (c < F::KCH && key0 + row < Nk && d < dh) kreg[it] = *reinterpret_cast<const uint4*>(kb + (long long)(key0 + row) * C + d);
+      if (c < F::KCH && key0 + row < Nk && d < dh) kreg[it] = *reinterpret_cast<const uint4*>(kb + (long long)(key0 + row) * ldk + d);
     }
 #pragma unroll
     for (int it = 0; it < F::VIT; ++it) {
@@ -243,15 +244,17 @@ int launch_fa(const FaParams& P, int Z, hipStream_t st) {
 
 bool dmx_flash_attn_ok(int dh, int C, int Nkp) { return dh >= 8 && dh <= 96 && (dh & 3) == 0 && (dh & 7) == 0 && (C & 7) == 0 && (Nkp & 7) == 0; }
 
-// q (B, Nq, C), k (B, Nk, C) channels-last with `heads` heads of dh = C / heads; vT (B*heads, dh, Nkp) = per-head V^T with
+// q (B, Nq, ldq), k (B, Nk, ldk) channels-last (row strides ldq / ldk >= C; 0 = C) with `heads` heads of dh = C / heads; vT (B*heads, dh, Nkp) = per-head V^T with
 // zero columns in [Nk, Nkp); o (B, Nq, C).  colbias: optional additive key bias (B, Nk) fp32.
 int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* vT, act_t* o, const float* colbias, int B, int Nq, int Nk,
-                       int Nkp, int C, int heads, float scale, hipStream_t st) {
+                       int Nkp, int C, int heads, float scale, hipStream_t st, int ldq, int ldk) {
   const int dh = C / heads;
-  if (!dmx_flash_attn_ok(dh, C, Nkp) || Nq < 1 || Nk < 1) return DMX_ERR_SHAPE;
+  if (ldq <= 0) ldq = C;
+  if (ldk <= 0) ldk = C;
+  if (!dmx_flash_attn_ok(dh, C, Nkp) || Nq < 1 || Nk < 1 || (ldq & 7) || (ldk & 7)) return DMX_ERR_SHAPE;
   FaParams P;
   P.q = q; P.k = k; P.vT = vT; P.o = o; P.colbias = colbias;
-  P.Nq = Nq; P.Nk = Nk; P.Nkp = Nkp; P.C = C; P.heads = heads; P.dh = dh;
+  P.Nq = Nq; P.Nk = Nk; P.Nkp = Nkp; P.C = C; P.heads = heads; P.dh = dh; P.ldq = ldq; P.ldk = ldk;
   P.c = scale * 1.4426950408889634f;
   const int Z = B * heads;
   const int rec = dmx_prof_open(st);

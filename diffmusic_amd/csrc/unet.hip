@@ -25,9 +25,24 @@ struct AttnLayer {
     to_v = make_linear(ps, pre + ".to_v", cross_dim, dim, false, false);
     to_out = make_linear(ps, pre + ".to_out.0", dim, dim, true, false);
   }
+  ConvLayer to_qkv;           // self-attention only: one projection with the three packed weights stacked along N
+  bool fused = false;
   int pack(ParamStore& ps, hipStream_t st) {
     CTRY(pack_layer(ps, to_q, st)); CTRY(pack_layer(ps, to_k, st));
     CTRY(pack_layer(ps, to_v, st)); CTRY(pack_layer(ps, to_out, st));
+    if (to_k.Ci == C && to_k.Cip == to_q.Cip && to_q.Cop == C) {
+      const size_t one = (size_t)C * to_q.Cip * sizeof(act_t);
+      act_t* w = (act_t*)ps.dalloc(3 * one);
+      if (!w) return DMX_ERR_PARAM;
+      (void)hipMemcpyAsync(w, to_q.wf[0], one, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync((char*)w + one, to_k.wf[0], one, hipMemcpyDeviceToDevice, st);
+      (void)hipMemcpyAsync((char*)w + 2 * one, to_v.wf[0], one, hipMemcpyDeviceToDevice, st);
+      to_qkv = to_q;
+      to_qkv.Co = to_qkv.Cop = 3 * C;
+      to_qkv.wf.assign(1, w);
+      to_qkv.has_bias = false;
+      fused = getenv("DMX_NO_QKV_FUSE") == nullptr;
+    }
     return DMX_OK;
   }
   // hres += to_out(attn(l, ctx)) ; l (B,N,C) normalised input, ctx (B,Nc,Cc) or nullptr (self)
@@ -36,15 +51,22 @@ struct AttnLayer {
     const size_t mk = A.mark();
     const act_t* kv_in = ctx ? ctx : l;
     const int Nk = ctx ? Nc : N;
-    act_t* q = A.bf((size_t)B * N * C);
-    act_t* k = A.bf((size_t)B * Nk * C);
-    act_t* v = A.bf((size_t)B * Nk * C);
     act_t* o = A.bf((size_t)B * N * C);
     Epi e;
-    CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
-    CRUN(linear_fwd(to_k, kv_in, to_k.Cip, k, C, (long long)B * Nk, e, cx.st));
-    CRUN(linear_fwd(to_v, kv_in, to_v.Cip, v, C, (long long)B * Nk, e, cx.st));
-    CTRY(attention_core(cx, q, k, v, o, B, N, Nk, C, heads, nullptr, colbias));
+    if (!ctx && fused) {
+      // self-attention: q | k | v come out of one GEMM (N = 3C) and are consumed as strided slices
+      act_t* qkv = A.bf((size_t)B * N * 3 * C);
+      CRUN(linear_fwd(to_qkv, l, to_q.Cip, qkv, 3 * C, (long long)B * N, e, cx.st));
+      CTRY(attention_core(cx, qkv, qkv + C, qkv + 2 * C, o, B, N, N, C, heads, nullptr, colbias, 3 * C, 3 * C, 3 * C));
+    } else {
+      act_t* q = A.bf((size_t)B * N * C);
+      act_t* k = A.bf((size_t)B * Nk * C);
+      act_t* v = A.bf((size_t)B * Nk * C);
+      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
+      CRUN(linear_fwd(to_k, kv_in, to_k.Cip, k, C, (long long)B * Nk, e, cx.st));
+      CRUN(linear_fwd(to_v, kv_in, to_v.Cip, v, C, (long long)B * Nk, e, cx.st));
+      CTRY(attention_core(cx, q, k, v, o, B, N, Nk, C, heads, nullptr, colbias));
+    }
     Epi er; er.flags = EPI_RESID; er.R = hres;
     CRUN(linear_fwd(to_out, o, C, hres, C, (long long)B * N, er, cx.st));
     A.release(mk);
