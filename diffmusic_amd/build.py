@@ -30,7 +30,7 @@ def build_library(force=False, verbose=False):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -38,6 +38,13 @@ def build_library(force=False, verbose=False):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        # kernels must not touch scratch: a demoted register array once doubled the write traffic of every GEMM epilogue
+        name = None
+        for line in r.stderr.splitlines():
+            if "Function Name:" in line:
+                name = line.split("Function Name:")[1].split()[0]
+            elif "ScratchSize [bytes/lane]:" in line and int(line.split("ScratchSize [bytes/lane]:")[1].split()[0]) > 0:
+                print(f"WARNING: kernel {name} uses scratch memory ({line.split(':')[-1].split('[')[0].strip()} bytes/lane)", file=sys.stderr, flush=True)
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))

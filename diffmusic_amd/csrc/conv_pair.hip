@@ -31,6 +31,7 @@ struct PairParams {
   int loA, hiA, loB, hiB;
   int off0A, dA, off0B, dB;              // slab row read by tap j of a stage: off0 + j * d  (taps are affine: j*dil - pad or pad - j*dil)
   int single;
+  int r_from_slab;                       // stage B's residual is stage A's input: take it from the LDS slab, not from HBM
 };
 
 template <int C>
@@ -131,7 +132,9 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     for (int it = 0; it < K::SLAB_IT; ++it) {
       const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = tfirst + row;
       sv[it] = make_uint4(0, 0, 0, 0);
+#ifndef DMX_PAIR_NOLOAD
       if (row < nrows && t >= 0 && t < T) sv[it] = *reinterpret_cast<const uint4*>(src + ((long long)b * T + t) * C + piece * 8);
+#endif
     }
     const bool masked = !single && (P.a.flags & EPI_MASK);
     uint4 mv[CPR];
@@ -228,10 +231,22 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     }
   };
 
+  uint2 rpre[4 * FN];
+#pragma unroll
+  for (int i = 0; i < 4 * FN; ++i) rpre[i] = make_uint2(0, 0);
   if (!single) {
     // ---- stage A: 256 intermediate rows, row i <-> t = t0 - loB + i
     zero_acc();
     run_stage(false, stepsA, 0);
+    if (P.r_from_slab) {
+      // the residual of stage B is the input of stage A: output row r (t = t0 + r) is slab row r + loA + loB; keep this lane's
+      // accumulator-layout pieces in registers before the slab is overwritten by the intermediate
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int n = 0; n < FN; ++n)
+          rpre[i * FN + n] = *reinterpret_cast<const uint2*>(slab + (wave * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (n * 16 + lq * 4) * 2);
+    }
     // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
     const int fa = P.a.flags;
     const float aslope = P.a.act_slope, mslope = P.a.mask_slope;
@@ -266,7 +281,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
 #pragma unroll
       for (int it = 0; it < CPR; ++it) {
         const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+#ifdef DMX_PAIR_NOMID
+        if (row == -12345)
+#else
         if (row >= P.loB && row < P.loB + P.BMo && t < T)
+#endif
           *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
       }
     }
@@ -281,7 +300,11 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     static_assert(EPI_WAVE_BYTES * 4 <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
     const int mbase = b * T + t0;
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
-    gemm_epilogue_lds<4, FN>(P.b, acc, mbase + wave * 64, 0, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend);
+#ifdef DMX_PAIR_NOEPI
+    if (P.b.alpha == 12345.f)
+#endif
+    gemm_epilogue_lds_impl<4, FN>(P.b, acc, mbase + wave * 64, 0, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
+                                  !single && P.r_from_slab != 0);
   }
 }
 
@@ -349,6 +372,7 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   P.T = b.Wq;
   P.BMo = a ? PAIR_ROWS - hb.lo - hb.hi : PAIR_ROWS;
   P.nb = cdiv(P.T, P.BMo);
+  P.r_from_slab = (a && (b.flags & EPI_RESID) && b.R == a->A && b.ldr == b.N) ? 1 : 0;
   const int nclips = b.M / P.T;
   const long long grid = (long long)nclips * P.nb;
   if (grid > 0x7fffffffLL) return DMX_ERR_SHAPE;
@@ -356,7 +380,7 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   double fl = 2.0 * b.M * (double)b.N * b.K;
   double by = 2.0 * b.M * (double)C * 2.0;                     // input + output
   if (a) { fl += 2.0 * a->M * (double)a->N * a->K; if (a->flags & EPI_LRELU2) by += 2.0 * b.M * (double)C; if (a->flags & EPI_MASK) by += 2.0 * b.M * (double)C; }
-  if (b.flags & EPI_RESID) by += 2.0 * b.M * (double)C;
+  if ((b.flags & EPI_RESID) && !P.r_from_slab) by += 2.0 * b.M * (double)C;
   if (b.flags & EPI_MASK) by += 2.0 * b.M * (double)C;
   if (b.flags & EPI_ACCUM) by += 2.0 * b.M * (double)C;
   if ((b.flags & EPI_LRELU2) && !(b.flags & EPI_NO_C)) by += 2.0 * b.M * (double)C;

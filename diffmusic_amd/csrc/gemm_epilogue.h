@@ -98,8 +98,11 @@ struct EpiChunk { static constexpr int IB = (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 
 // row segments (16 B per lane, TN*2-byte contiguous runs = whole cache lines) and is exchanged with the
 // accumulator layout through LDS.  Rows are handled in chunks of CH <= 64 to fit 8 waves in the stage buffers.
 template <int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
-                                                  long long coff, int HqWq, char* wl, int mlimit = 0x7fffffff) {
+__device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
+                                                       long long coff, int HqWq, char* wl, int mlimit,
+                                                       const uint2 (&rpre)[FM * FN], const bool use_rpre) {
+  // rpre: the residual tile already in registers in accumulator layout ([FM][FN] 8-byte pieces; conv_pair.hip takes it from
+  // its LDS slab) -- the residual tensor is then not read from HBM again
   constexpr int CH = EpiChunk<FM>::CH;
   constexpr int IB = EpiChunk<FM>::IB;
   constexpr int TNB = FN * 32;            // bytes per tile row
@@ -226,7 +229,18 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
         }
       }
     }
-    if (flags & EPI_RESID) {
+    if ((flags & EPI_RESID) && use_rpre) {
+      const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const uint2 q = rpre[(h * IB + ii) * FN + j];
+          const float x0 = alo(q.x), x1 = ahi(q.x), x2 = alo(q.y), x3 = ahi(q.y);
+          f32x4& a = acc[h * IB + ii][j];
+          a[0] += fminf(x0, x0 * is); a[1] += fminf(x1, x1 * is); a[2] += fminf(x2, x2 * is); a[3] += fminf(x3, x3 * is);
+        }
+    } else if (flags & EPI_RESID) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
       stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
         // x > 0 ? x : x * is  ==  min(x, x * is) for is >= 1 (is = 1 / leaky slope, or exactly 1 for a plain residual)
@@ -262,6 +276,13 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc
     }
   }
 #undef DMX_LDS_SYNC
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
+                                                  long long coff, int HqWq, char* wl, int mlimit = 0x7fffffff) {
+  const uint2 none[FM * FN] = {};
+  gemm_epilogue_lds_impl<FM, FN>(p, acc, m0, n0, lane, coff, HqWq, wl, mlimit, none, false);
 }
 
 }  // namespace
