@@ -86,9 +86,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
-// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM)  (5-tile chunks for FM = 10 measured slower)
+// rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM); 80- and 32-row chunks both measured slower
+#ifndef DMX_EPI_IB
+#define DMX_EPI_IB 4
+#endif
 template <int FM>
-struct EpiChunk { static constexpr int IB = (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 3 : (FM % 2 == 0) ? 2 : 1; static constexpr int CH = IB * 16; };
+struct EpiChunk { static constexpr int IB = (FM % DMX_EPI_IB == 0) ? DMX_EPI_IB : (FM % 4 == 0) ? 4 : (FM % 3 == 0) ? 3 : (FM % 2 == 0) ? 2 : 1; static constexpr int CH = IB * 16; };
 
 // ---------------------------------------------------------------------------------------------
 // LDS-staged epilogue for fp16 outputs.  The MFMA accumulator layout gives a lane 4 channels of one pixel
@@ -113,7 +116,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   static_assert(CH % RPI == 0, "chunk rows must be a multiple of the rows per wave-instruction");
   const int lr = lane & 15, lq = lane >> 4;
   const int rr = lane / CPR, cch = lane - rr * CPR;
-  long long* tab = reinterpret_cast<long long*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range), general map only
+  int* tab = reinterpret_cast<int*>(wl + CH * PITCH);   // output row index per tile row (-1: out of range), general map only
   const int flags = p.flags;
   const int ncol = n0 + cch * 8;
   const bool col_ok = ncol < p.N;
@@ -121,24 +124,58 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   // stride-1 convolutions and plain GEMMs write GEMM row m to output row m: no index table, no divisions
   const bool ident = p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.Ho == p.Hq && p.Wo == p.Wq;
 #define DMX_LDS_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+  // the channel bias depends on the column only: fetch it once, ahead of everything else (inside the chunk loop each chunk
+  // paid an exposed L2 round trip for it)
+  float4 bcol[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + j * 16 + lq * 4;
+    bcol[j] = ((flags & EPI_BIAS) && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // Optional (-DDMX_EPI_PREFETCH, off): fetch the first tensor a chunk reads (mask source, else residual, else the accumulated
+  // C) one chunk ahead into `pre`.  Measured slower on the benchmark step (+0.6 ms with 32-row chunks, +2 ms with 64-row chunks,
+  // where the extra 32 VGPRs push the 256x256 tile into scratch): the epilogue is bound by VALU issue and LDS round trips of
+  // the two waves per SIMD, not by this latency.
+  const int first = (flags & EPI_MASK) ? 0 : ((flags & EPI_RESID) && !use_rpre) ? 1 : (flags & EPI_ACCUM) ? 2 : -1;
+  const act_t* Gfirst = first == 0 ? p.X : first == 1 ? p.R : reinterpret_cast<const act_t*>(p.C);
+  const int ldfirst = first == 0 ? p.ldx : first == 1 ? p.ldr : p.ldc;
+  const bool prefetch = ident && first >= 0;
+  uint4 pre[NIT];
+  auto issue_pre = [&](int hh) {
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int m = m0 + hh * CH + it * RPI + rr;
+      const bool ok = m < mend && col_ok;
+      const long long off = ok ? (long long)m * ldfirst + ncol : 0ll;
+#ifndef DMX_EPI_NOLOAD
+      pre[it] = *reinterpret_cast<const uint4*>(Gfirst + coff + off);
+#else
+      pre[it] = make_uint4(0, 0, 0, 0);
+#endif
+      if (!ok) pre[it] = make_uint4(0, 0, 0, 0);
+    }
+  };
+#ifdef DMX_EPI_PREFETCH
+  if (prefetch) issue_pre(0);
+#endif
 #pragma unroll
   for (int h = 0; h < FM / IB; ++h) {
     // ---- output row of each tile row this lane touches in the row-major phases
-    long long orows[NIT];
+    int orows[NIT];          // output row (< 2^31 rows per tensor) or -1
     if (ident) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int m = m0 + h * CH + it * RPI + rr;
-        orows[it] = m < mend ? (long long)m : -1ll;
+        orows[it] = m < mend ? m : -1;
       }
     } else {
       if (lane < CH) {
         const int m = m0 + h * CH + lane;
-        long long orow = -1;
+        int orow = -1;
         if (m < mend) {
           const int b = m / HqWq, rem = m - b * HqWq;
           const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-          orow = ((long long)b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
+          orow = (b * p.Ho + (qy * p.osy + p.ooy)) * p.Wo + (qx * p.osx + p.oox);
         }
         tab[lane] = orow;
       }
@@ -149,21 +186,31 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     }
     // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`.  All loads of a chunk are issued back to
     // back from always-valid addresses (out-of-range rows read element 0 and are zeroed): one exposed latency per tensor.
-    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
-      uint4 v[NIT];
-#pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const bool ok = orows[it] >= 0 && col_ok;
-        const long long off = ok ? orows[it] * ld + ncol : 0ll;
-#ifndef DMX_EPI_NOLOAD
-        v[it] = *reinterpret_cast<const uint4*>(G + coff + off);
+    auto stage_in = [&](int which, const act_t* G, int ld, auto&& f) {
+#ifdef DMX_EPI_PREFETCH
+      const bool from_pre = prefetch && which == first;
 #else
-        v[it] = make_uint4(0, 0, 0, 0);
+      const bool from_pre = false;
 #endif
-        if (!ok) v[it] = make_uint4(0, 0, 0, 0);
-      }
+      if (from_pre) {
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = v[it];
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = pre[it];
+      } else {
+        uint4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+          const bool ok = orows[it] >= 0 && col_ok;
+          const long long off = ok ? (long long)orows[it] * ld + ncol : 0ll;
+#ifndef DMX_EPI_NOLOAD
+          v[it] = *reinterpret_cast<const uint4*>(G + coff + off);
+#else
+          v[it] = make_uint4(0, 0, 0, 0);
+#endif
+          if (!ok) v[it] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = v[it];
+      }
       DMX_LDS_SYNC();
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
@@ -184,24 +231,28 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
         }
       DMX_LDS_SYNC();
-      uint4 v[NIT];
+      constexpr int HN = NIT > 4 ? NIT / 2 : NIT;      // row-major read / store in groups of <= 4 instructions (register pressure)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) v[it] = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
+      for (int g0 = 0; g0 < NIT; g0 += HN) {
+      uint4 v[HN];
+#pragma unroll
+      for (int it = 0; it < HN; ++it) v[it] = *reinterpret_cast<const uint4*>(wl + ((g0 + it) * RPI + rr) * PITCH + cch * 16);
       // (no explicit wait here: the stores depend on v through registers, and a later LDS write of this wave cannot pass
       //  these reads -- LDS operations of one wave complete in order.  A "memory"-clobbering asm at this point made hipcc
       //  keep v[] in scratch: every output byte was written twice.)
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
+      for (int it = 0; it < HN; ++it) {
 #ifndef DMX_EPI_NOSTORE
-        if (orows[it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + orows[it] * ld + ncol) = v[it];
+        if (orows[g0 + it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
 #else
-        if (orows[it] == -12345 && col_ok) *reinterpret_cast<uint4*>(G + coff + orows[it] * ld + ncol) = v[it];
+        if (orows[g0 + it] == -12345 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
 #endif
+      }
       }
     };
     if (flags & EPI_MASK) {
       const float sl = p.mask_slope;
-      stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+      stage_in(0, p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
         a[0] *= x0 > 0.f ? 1.f : sl; a[1] *= x1 > 0.f ? 1.f : sl; a[2] *= x2 > 0.f ? 1.f : sl; a[3] *= x3 > 0.f ? 1.f : sl;
       });
     }
@@ -219,7 +270,11 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           if (n >= p.N) continue;
           f32x4& a = acc[h * IB + ii][j];
           if (flags & EPI_BIAS) {
+#ifdef DMX_EPI_BIAS_INLOOP
             const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+#else
+            const float4 bb = bcol[j];
+#endif
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
           if (flags & EPI_ROWBIAS) {
@@ -242,7 +297,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         }
     } else if (flags & EPI_RESID) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
-      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+      stage_in(1, p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
         // x > 0 ? x : x * is  ==  min(x, x * is) for is >= 1 (is = 1 / leaky slope, or exactly 1 for a plain residual)
         a[0] += fminf(x0, x0 * is); a[1] += fminf(x1, x1 * is); a[2] += fminf(x2, x2 * is); a[3] += fminf(x3, x3 * is);
       });
@@ -255,13 +310,16 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] *= al; a[1] *= al; a[2] *= al; a[3] *= al; }
     }
     if (flags & EPI_ACCUM)
-      stage_in(reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+      stage_in(2, reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
     if (flags & EPI_TANH) {
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
     }
+#ifdef DMX_EPI_PREFETCH
+    if (prefetch && h + 1 < FM / IB) issue_pre(h + 1);
+#endif
     if (!(flags & EPI_NO_C)) {
       stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
       DMX_LDS_SYNC();
