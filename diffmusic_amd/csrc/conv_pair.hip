@@ -1,4 +1,4 @@
-// Fused pair of stride-1 dilated 1-D convolutions for the narrow (C = 32 / 64) HiFi-GAN resblock stages.
+// Fused pair of stride-1 dilated 1-D convolutions for the narrow (C = 32 / 64 / 128) HiFi-GAN resblock stages.
 //
 // A HiFi-GAN resblock step is conv1 -> leaky-relu -> conv2 -> (+ residual)  (transformers
 // modeling_speecht5.py HifiGanResidualBlock.forward; reached from the reference through
@@ -37,19 +37,23 @@ struct PairParams {
 template <int C>
 struct PairCfg {
   // +32 B: a ds_read_b128 lane group is 8 rows at one k-quarter plus 8 other rows at the next (MI355X_MICROARCH.md, LDS);
-  // with a pitch of 2C+32 bytes (24 / 40 dwords) those 16 four-dword spans hit 16 different bank quads
+  // with a pitch of 2C+32 bytes (24 / 40 / 72 dwords) those 16 four-dword spans hit 16 different bank quads
   static constexpr int PITCH = 2 * C + 32;
   static constexpr int CPR = C / 8;                // 16-byte chunks per row
-  static constexpr int FN = C / 16;
-  static constexpr int TPS = 64 / C;               // taps per 64-deep K step
+  static constexpr int WN = C > 64 ? C / 64 : 1;   // column groups of 64 channels (C = 128: two), one wave each per row group
+  static constexpr int NW = 4 * WN;                // waves: 4 row groups of 64 rows x WN column groups
+  static constexpr int NT = NW * 64;
+  static constexpr int FN = C / 16 / WN;           // 16-wide n tiles per wave
   static constexpr int SLAB_ROWS = PAIR_ROWS + PAIR_HALO;
   static constexpr int SLAB_BYTES = SLAB_ROWS * PITCH;
   static constexpr int TILE = C * 128;             // weights of one K step: C rows x 64 k, 128-byte rows, XOR-swizzled chunks
   static constexpr int NS = 3;
-  static constexpr int PER = TILE / 1024 / 4;      // LDS-DMA instructions per wave per K step
-  static constexpr int SLAB_IT = (SLAB_ROWS * CPR + 255) / 256;
+  static constexpr int PER = TILE / 1024 / NW;     // LDS-DMA instructions per wave per K step
+  static constexpr int SLAB_IT = (SLAB_ROWS * CPR + NT - 1) / NT;
+  static constexpr int BITS_IT = PAIR_ROWS * CPR / NT;
   static constexpr int BITS_BYTES = PAIR_ROWS * CPR;
   static constexpr int LDS_BYTES = SLAB_BYTES + NS * TILE + BITS_BYTES;
+  static_assert(PER >= 1 && PAIR_ROWS * CPR % NT == 0, "tile / thread-count mismatch");
 };
 
 template <int FN>
@@ -76,9 +80,9 @@ __device__ __forceinline__ void pair_settle(PairFrags<2>& f) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
+__global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairParams P) {
   using K = PairCfg<C>;
-  constexpr int PITCH = K::PITCH, CPR = K::CPR, FN = K::FN, NS = K::NS, PER = K::PER, TILE = K::TILE;
+  constexpr int PITCH = K::PITCH, CPR = K::CPR, FN = K::FN, NS = K::NS, PER = K::PER, TILE = K::TILE, NT = K::NT, NW = K::NW, WN = K::WN;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* ring = smem;                                   // 1 KiB-aligned LDS-DMA targets first
   char* slab = smem + NS * TILE;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
 
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rg = wave / WN, cg = wave - rg * WN;       // row group (64 intermediate rows) and column group (64 channels) of this wave
   int bid = blockIdx.x;
   {  // XCD-aware remap: neighbouring time tiles (shared halos, same weights) land on the same L2
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     char* dst = ring + (g % NS) * TILE;
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int j = i * 4 + wave;
+      const int j = i * NW + wave;
       const unsigned voff = ok ? (unsigned)(j * 8 + lrow) * ldw2 + (unsigned)kel * 2u : PAIR_OOB;
       if (inA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff, 0, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(dst + j * 1024), 16, voff, 0, 0, 0);
@@ -130,25 +135,25 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     uint4 sv[K::SLAB_IT];
 #pragma unroll
     for (int it = 0; it < K::SLAB_IT; ++it) {
-      const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = tfirst + row;
+      const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = tfirst + row;
       sv[it] = make_uint4(0, 0, 0, 0);
 #ifndef DMX_PAIR_NOLOAD
       if (row < nrows && t >= 0 && t < T) sv[it] = *reinterpret_cast<const uint4*>(src + ((long long)b * T + t) * C + piece * 8);
 #endif
     }
     const bool masked = !single && (P.a.flags & EPI_MASK);
-    uint4 mv[CPR];
+    uint4 mv[K::BITS_IT];
     if (masked) {
 #pragma unroll
-      for (int it = 0; it < CPR; ++it) {
-        const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+      for (int it = 0; it < K::BITS_IT; ++it) {
+        const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
         mv[it] = make_uint4(0, 0, 0, 0);
         if (t >= 0 && t < T) mv[it] = *reinterpret_cast<const uint4*>(P.a.X + ((long long)b * T + t) * C + piece * 8);
       }
     }
 #pragma unroll
     for (int it = 0; it < K::SLAB_IT; ++it) {
-      const int c = tid + it * 256, row = c / CPR, piece = c % CPR;
+      const int c = tid + it * NT, row = c / CPR, piece = c % CPR;
       if (row < K::SLAB_ROWS) *reinterpret_cast<uint4*>(slab + row * PITCH + piece * 16) = sv[it];
     }
     if (masked) {
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
         return lo | (hi << 1);
       };
 #pragma unroll
-      for (int it = 0; it < CPR; ++it) {
-        const int c = tid + it * 256;
+      for (int it = 0; it < K::BITS_IT; ++it) {
+        const int c = tid + it * NT;
         s_bits[c] = (unsigned char)(pos2(mv[it].x) | (pos2(mv[it].y) << 2) | (pos2(mv[it].z) << 4) | (pos2(mv[it].w) << 6));
       }
     }
@@ -175,15 +180,17 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
       for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
   using Frags = PairFrags<FN>;
-  const unsigned xlane = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(slab + (wave * 64 + lr) * PITCH + lq * 16);
-  const unsigned wlane0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + lr * 128 + (((0 * 4 + lq) ^ (lr & 7)) << 4));
-  const unsigned wlane1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + lr * 128 + (((1 * 4 + lq) ^ (lr & 7)) << 4));
+  const unsigned xlane = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(slab + (rg * 64 + lr) * PITCH + lq * 16);
+  const unsigned wlane0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + (cg * 64 + lr) * 128 + (((0 * 4 + lq) ^ (lr & 7)) << 4));
+  const unsigned wlane1 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + (cg * 64 + lr) * 128 + (((1 * 4 + lq) ^ (lr & 7)) << 4));
   // fragments of K step s of a stage (global step g): x rows shifted by the tap, weights from ring tile g
   auto load_frags = [&](Frags& f, bool isB, int sidx, int g) {
     const int off0 = isB ? P.off0B : P.off0A, dd = isB ? P.dB : P.dA, kk = isB ? kB : kA;
     unsigned xa0, xa1;
-    if constexpr (C == 64) {
-      xa0 = xlane + (unsigned)((off0 + sidx * dd) * PITCH);
+    if constexpr (C >= 64) {
+      constexpr int SPT = C / 64;                                    // K steps per tap (C = 128: one per 64-channel half)
+      const int tp = sidx / SPT, kh = sidx - tp * SPT;
+      xa0 = xlane + (unsigned)((off0 + tp * dd) * PITCH + kh * 128);
       xa1 = xa0 + 64u;
     } else {
       const int tp0 = 2 * sidx, tp1 = (2 * sidx + 1 < kk) ? 2 * sidx + 1 : kk - 1;   // a padded tap has zero weights: any valid rows
@@ -245,19 +252,19 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int n = 0; n < FN; ++n)
-          rpre[i * FN + n] = *reinterpret_cast<const uint2*>(slab + (wave * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (n * 16 + lq * 4) * 2);
+          rpre[i * FN + n] = *reinterpret_cast<const uint2*>(slab + (rg * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (cg * 64 + n * 16 + lq * 4) * 2);
     }
     // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
     const int fa = P.a.flags;
     const float aslope = P.a.act_slope, mslope = P.a.mask_slope;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = wave * 64 + i * 16 + lr;
+      const int row = rg * 64 + i * 16 + lr;
       const int t = t0 - P.loB + row;
       const bool inside = t >= 0 && t < T;
 #pragma unroll
       for (int n = 0; n < FN; ++n) {
-        const int ch = n * 16 + lq * 4;
+        const int ch = cg * 64 + n * 16 + lq * 4;
         float v[4] = {acc[i][n][0], acc[i][n][1], acc[i][n][2], acc[i][n][3]};
         if (fa & EPI_MASK) {
           const unsigned bits = (unsigned)s_bits[row * CPR + (ch >> 3)] >> (ch & 4);
@@ -279,8 +286,8 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
     __syncthreads();
     if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only, full rows
 #pragma unroll
-      for (int it = 0; it < CPR; ++it) {
-        const int c = tid + it * 256, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+      for (int it = 0; it < K::BITS_IT; ++it) {
+        const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
 #ifdef DMX_PAIR_NOMID
         if (row == -12345)
 #else
@@ -297,13 +304,13 @@ __global__ __launch_bounds__(256) void conv_pair_kernel(const PairParams P) {
   __syncthreads();
   {
     constexpr int EPI_WAVE_BYTES = 64 * (FN * 32 + 16) + 64 * 12;
-    static_assert(EPI_WAVE_BYTES * 4 <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
+    static_assert(EPI_WAVE_BYTES * NW <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
     const int mbase = b * T + t0;
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
 #ifdef DMX_PAIR_NOEPI
     if (P.b.alpha == 12345.f)
 #endif
-    gemm_epilogue_lds_impl<4, FN>(P.b, acc, mbase + wave * 64, 0, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
+    gemm_epilogue_lds_impl<4, FN>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
                                   !single && P.r_from_slab != 0);
   }
 }
@@ -337,7 +344,8 @@ bool g_pair_enabled = getenv("DMX_NO_PAIR") == nullptr;
 bool dmx_conv_pair_eligible(const GemmDesc* a, const GemmDesc& b) {
   if (!g_pair_enabled) return false;
   const int C = b.N, T = b.Wq;
-  if (C != 32 && C != 64) return false;
+  static const bool c128 = getenv("DMX_NO_PAIR128") == nullptr;
+  if (C != 32 && C != 64 && !(C == 128 && c128)) return false;
   if (T < 1) return false;
   const int bflags = EPI_BIAS | EPI_RESID | EPI_RESID_INV | EPI_ACCUM | EPI_MASK | EPI_LRELU2 | EPI_NO_C;
   if (!stage_ok(b, C, T, bflags) || !halo_of(b).ok) return false;
@@ -385,15 +393,15 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   if (b.flags & EPI_ACCUM) by += 2.0 * b.M * (double)C;
   if ((b.flags & EPI_LRELU2) && !(b.flags & EPI_NO_C)) by += 2.0 * b.M * (double)C;
   const int rec = dmx_prof_open(st);
-  if (C == 32) {
-    static bool attr32 = false;
-    if (!attr32) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<32>::LDS_BYTES); attr32 = true; }
-    hipLaunchKernelGGL(conv_pair_kernel<32>, dim3((unsigned)grid), dim3(256), PairCfg<32>::LDS_BYTES, st, P);
-  } else {
-    static bool attr64 = false;
-    if (!attr64) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<64>::LDS_BYTES); attr64 = true; }
-    hipLaunchKernelGGL(conv_pair_kernel<64>, dim3((unsigned)grid), dim3(256), PairCfg<64>::LDS_BYTES, st, P);
-  }
+  auto launch = [&](auto tag) {
+    constexpr int CC = decltype(tag)::value;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<CC>::LDS_BYTES); attr = true; }
+    hipLaunchKernelGGL(conv_pair_kernel<CC>, dim3((unsigned)grid), dim3(PairCfg<CC>::NT), PairCfg<CC>::LDS_BYTES, st, P);
+  };
+  if (C == 32) launch(std::integral_constant<int, 32>{});
+  else if (C == 64) launch(std::integral_constant<int, 64>{});
+  else launch(std::integral_constant<int, 128>{});
   dmx_prof_close(rec, st, fl, by, b.M, b.N, (a ? a->K : 0) + b.K, b.ntaps, b.flags, a ? 21 : 20);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }

@@ -17,7 +17,7 @@ def run(da, db):
     L.check(L.lib().dmx_conv_pair_raw(C.byref(da) if da is not None else None, C.byref(db), C.sizeof(db), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "pair")
 
 adt = L.act_dtype()
-cases = [(8, 160032, 32, 3, 1), (8, 160032, 32, 7, 3), (8, 160032, 32, 11, 5), (8, 80016, 64, 3, 1), (8, 80016, 64, 7, 3), (8, 80016, 64, 11, 5)]
+cases = [(8, 40008, 128, 3, 1), (8, 40008, 128, 7, 3), (8, 40008, 128, 11, 5), (8, 160032, 32, 3, 1), (8, 160032, 32, 7, 3), (8, 160032, 32, 11, 5), (8, 80016, 64, 3, 1), (8, 80016, 64, 7, 3), (8, 80016, 64, 11, 5)]
 for B, T, Cc, k, dil in cases:
     g = torch.Generator().manual_seed(0)
     xa = torch.randn(B, T, Cc, generator=g).to(adt).cuda()

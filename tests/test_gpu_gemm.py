@@ -137,7 +137,8 @@ def _pair_run(L, da, db):
 
 
 @pytest.mark.parametrize("B,T,Cc,k,dil", [(2, 1000, 64, 3, 1), (1, 2049, 64, 11, 5), (3, 700, 32, 7, 3), (2, 5000, 32, 11, 5),
-                                          (1, 100, 32, 3, 1), (2, 256, 64, 7, 1), (1, 4097, 64, 3, 5)])
+                                          (1, 100, 32, 3, 1), (2, 256, 64, 7, 1), (1, 4097, 64, 3, 5),
+                                          (2, 1000, 128, 3, 1), (1, 2049, 128, 11, 5), (2, 777, 128, 7, 3)])
 def test_fused_resblock_pair_forward(B, T, Cc, k, dil):
     """conv1(dilated) -> leaky-relu -> conv2 -> + reconstructed residual, the HiFi-GAN resblock step
     (modeling_speecht5.py HifiGanResidualBlock.forward), fused in one launch; checked against torch fp32 and
@@ -178,7 +179,7 @@ def test_fused_resblock_pair_forward(B, T, Cc, k, dil):
 
 
 @pytest.mark.parametrize("B,T,Cc,k,dil", [(2, 1000, 64, 3, 1), (1, 2049, 64, 11, 5), (3, 700, 32, 7, 3), (2, 3000, 32, 11, 5),
-                                          (1, 100, 64, 7, 5)])
+                                          (1, 100, 64, 7, 5), (2, 1000, 128, 3, 1), (1, 2049, 128, 11, 5), (1, 300, 128, 7, 3)])
 def test_fused_resblock_pair_backward(B, T, Cc, k, dil):
     """dgrad(conv2) -> leaky-relu' -> dgrad(conv1) -> leaky-relu' + residual, accumulated into an existing gradient."""
     from diffmusic_amd import _lib as L
