@@ -98,6 +98,7 @@ _SIGS = {
     "dmx_audio_transform_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
     "dmx_audio_stft_mag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dmx_audio_stft_mag_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_melscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "dmx_mask_apply": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_l2_loss": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_void_p]),

@@ -73,6 +73,16 @@ int dmx_audio_stft_mag(dmx_audio* a, const float* wav, long long wav_stride, flo
   if (rc) return rc;
   return dmx_stft_mag(s.X, mag, batch, T, a->bins, a->Npad, ST(stream));
 }
+int dmx_audio_stft_mag_bwd(dmx_audio* a, const float* dmag, float* dwav, long long dwav_stride, void* state, int batch, int L,
+                           int accumulate, void* stream) {
+  const int T = frames_of(a, L);
+  AudioState s = carve(a, state, batch, L);          // s.X: spectrum kept by the last dmx_audio_stft_mag on this state
+  int rc = dmx_stft_mag_bwd(s.X, dmag, s.Y, batch, T, a->bins, a->Npad, a->Kpad, ST(stream));
+  if (rc) return rc;
+  rc = dmx_stft_bwd_frames(s.Y, a->tableT, s.dframe, batch * T, a->n_fft, a->Kpad, ST(stream));
+  if (rc) return rc;
+  return dmx_overlap_add(s.dframe, dwav, dwav_stride, batch, T, L, a->n_fft, a->hop, accumulate, ST(stream));
+}
 int dmx_audio_melscale(dmx_audio* a, const float* mag, float* mel_out, int batch, int T, float lo, float hi, void* stream) {
   return dmx_melscale(mag, a->fb, mel_out, batch, T, a->bins, a->n_mels, lo, hi, ST(stream));
 }

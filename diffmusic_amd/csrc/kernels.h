@@ -55,6 +55,7 @@ int dmx_mel_fwd(const float* X, const float* fb, float* mel_lin, float* mel_out,
 int dmx_mel_bwd(const float* X, const float* fb, const float* mel_lin, const float* dmel, float* Y, int rows, int ldx, int ldy, int bins,
                 int n_mels, int power2, int to_db, float lo, float hi, hipStream_t st);
 int dmx_stft_mag(const float* X, float* mag, int B, int T, int bins, int ldx, hipStream_t st);
+int dmx_stft_mag_bwd(const float* X, const float* dmag, float* Y, int B, int T, int bins, int ldx, int ldy, hipStream_t st);
 int dmx_overlap_add(const float* dframe, float* dwav, long long out_stride, int B, int T, int L, int n_fft, int hop, int accumulate,
                     hipStream_t st);
 int dmx_l2_loss_grad(const float* ref, const float* pred, float* loss, float* dpred, int B, long long n, long long ref_stride, float gscale,

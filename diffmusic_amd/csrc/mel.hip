@@ -243,6 +243,26 @@ __global__ void stft_mag_kernel(const float* __restrict__ X, float* __restrict__
   mag[idx] = sqrtf(x.x * x.x + x.y * x.y);
 }
 
+// d|X| (B, bins, T) -> Y (B*T, ldy) with Y[2k] = g * re / |X|, Y[2k+1] = g * im / |X| (0 where |X| = 0, the subgradient
+// torch.abs uses); columns past 2*bins are zeroed so that the transposed STFT can consume the full row
+__global__ void stft_mag_bwd_kernel(const float* __restrict__ X, const float* __restrict__ dmag, float* __restrict__ Y, int B, int T,
+                                    int bins, int ldx, int ldy) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = ldy >> 1;
+  if (idx >= (long long)B * T * half) return;
+  const int k = (int)(idx % half);
+  const long long r = idx / half;
+  float2 y = make_float2(0.f, 0.f);
+  if (k < bins) {
+    const int t = (int)(r % T), b = (int)(r / T);
+    const float2 x = *reinterpret_cast<const float2*>(X + r * ldx + 2 * k);
+    const float m = sqrtf(x.x * x.x + x.y * x.y);
+    const float c = m > 0.f ? dmag[((long long)b * bins + k) * T + t] / m : 0.f;
+    y = make_float2(c * x.x, c * x.y);
+  }
+  *reinterpret_cast<float2*>(Y + r * ldy + 2 * k) = y;
+}
+
 // overlap-add of dframe (B*T, n_fft) back onto the waveform, folding the reflect padding
 __global__ void overlap_add_kernel(const float* __restrict__ dframe, float* __restrict__ dwav, long long out_stride, int B, int T, int L,
                                    int n_fft, int hop, int pad, int accumulate) {
@@ -368,6 +388,11 @@ int dmx_mel_bwd(const float* X, const float* fb, const float* mel_lin, const flo
 int dmx_stft_mag(const float* X, float* mag, int B, int T, int bins, int ldx, hipStream_t st) {
   const long long n = (long long)B * bins * T;
   hipLaunchKernelGGL(stft_mag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, mag, B, T, bins, ldx);
+  return CHECK_LAUNCH();
+}
+int dmx_stft_mag_bwd(const float* X, const float* dmag, float* Y, int B, int T, int bins, int ldx, int ldy, hipStream_t st) {
+  const long long n = (long long)B * T * (ldy >> 1);
+  hipLaunchKernelGGL(stft_mag_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, dmag, Y, B, T, bins, ldx, ldy);
   return CHECK_LAUNCH();
 }
 int dmx_overlap_add(const float* dframe, float* dwav, long long out_stride, int B, int T, int L, int n_fft, int hop, int accumulate,

@@ -84,6 +84,13 @@ class SpectralFrontend:
         L.check(L.lib().dmx_audio_stft_mag(self._h, _p(wav), wav.stride(0), _p(mag), _p(st), B, length, _stream()), "stft_mag")
         return mag
 
+    def stft_mag_bwd(self, dmag, length, dwav):
+        """dmag (B, bins, frames) w.r.t. the magnitude of the last stft_mag call -> dwav (B, >=length) (overwritten)."""
+        B = dmag.shape[0]
+        L.check(L.lib().dmx_audio_stft_mag_bwd(self._h, _p(dmag), _p(dwav), dwav.stride(0), _p(self._state), B, length, 0, _stream()),
+                "stft_mag_bwd")
+        return dwav
+
     def melscale(self, mag, lo=_NEG, hi=_POS):
         B, _, T = mag.shape
         mel = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=mag.device)
@@ -268,9 +275,16 @@ class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
         return self.noiser(mag) if self.noiser is not None else mag
 
     def guidance(self, wav, length, measurement, supervised_space):
-        if supervised_space != "mel_spectrogram":
-            raise NotImplementedError("phase retrieval guidance is implemented in the mel_spectrogram space")
         measurement = _as_f32_cuda(measurement)
+        if supervised_space == "wav_form":          # scheduling_dps.py:199-201: || y - |STFT(wav)| ||_2 on the raw magnitudes
+            mag = self.frontend.stft_mag(wav, length)
+            B = mag.shape[0]
+            loss, dmag = l2_loss(measurement.reshape(B, -1), mag.reshape(B, -1))
+            dwav = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)
+            self.frontend.stft_mag_bwd(dmag.reshape(mag.shape), length, dwav)
+            return loss, dwav
+        if supervised_space != "mel_spectrogram":
+            raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
         ref = self._ref(measurement, lambda m: self.frontend.melscale(m, -80.0, 80.0))
         pred = self.frontend.transform_fwd(wav, length, False, False, -80.0, 80.0)   # |STFT| -> MelScale -> clamp
         loss, dmel = l2_loss(ref, pred)

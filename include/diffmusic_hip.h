@@ -140,6 +140,11 @@ int dmx_audio_transform_bwd(dmx_audio* a, const float* dmel, float* dwav, long l
                             int power2, int to_db, float lo, float hi, int accumulate, void* stream);
 /* PhaseRetrievalOperator.forward: |torch.stft(wav)| as (B, n_fft/2+1, frames) fp32 */
 int dmx_audio_stft_mag(dmx_audio* a, const float* wav, long long wav_stride, float* mag, void* state, int batch, int L, void* stream);
+/* gradient of a loss on that magnitude (PhaseRetrievalOperator.forward, operator.py:156-163, differentiated by
+ * torch.autograd in scheduling_dps.py:199-212 when supervised_space == "wav_form"): dmag (batch, bins, frames) -> dwav;
+ * uses the spectrum the last dmx_audio_stft_mag left in `state` */
+int dmx_audio_stft_mag_bwd(dmx_audio* a, const float* dmag, float* dwav, long long dwav_stride, void* state, int batch, int L,
+                           int accumulate, void* stream);
 /* PhaseRetrievalOperator.transform on a given magnitude (B, bins, frames) -> (B, frames, n_mels) */
 int dmx_audio_melscale(dmx_audio* a, const float* mag, float* mel_out, int batch, int frames, float lo, float hi, void* stream);
 /* MusicInpaintingOperator.forward (operator.py:132-133): y[b,t] = x[b,t]*mask[t] (t<L), 0 for L<=t<Ly; mask NULL = copy */

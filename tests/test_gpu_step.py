@@ -63,7 +63,8 @@ CASES = [("dps", "music_inpainting", 0.0, 5e-4, "mel_spectrogram", 501), ("dps",
          ("mpgd", "music_inpainting", 0.0, 5e-3, "mel_spectrogram", 251), ("dsg", "phase_retrieval", 1.0, 0.08, "mel_spectrogram", 501),
          ("diffmusic", "music_inpainting", 1.0, 0.08, "mel_spectrogram", 501), ("dps", "identity", 0.5, 5e-4, "mel_spectrogram", 101),
          ("ddim", "identity", 0.0, 0.0, "mel_spectrogram", 501), ("mpgd", "super_resolution4", 0.0, 5e-3, "mel_spectrogram", 501),
-         ("dps", "super_resolution", 0.0, 5e-4, "wav_form", 251), ("dps", "music_dereverberation", 0.0, 5e-4, "mel_spectrogram", 501)]
+         ("dps", "super_resolution", 0.0, 5e-4, "wav_form", 251), ("dps", "music_dereverberation", 0.0, 5e-4, "mel_spectrogram", 501),
+         ("dps", "phase_retrieval", 0.0, 5e-4, "wav_form", 501)]
 
 
 @pytest.mark.parametrize("name,task,eta,rate,space,t", CASES)
