@@ -39,7 +39,7 @@ class GuidedDDIMScheduler:
     def __init__(self, operator=None, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
                  thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
-                 timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, *args, **kwargs):
+                 timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, per_clip_norm=True, *args, **kwargs):
         if prediction_type != "epsilon" or clip_sample or thresholding or rescale_betas_zero_snr:
             raise NotImplementedError("only epsilon prediction without clipping/thresholding (the reference's configs) is built")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
@@ -64,6 +64,10 @@ class GuidedDDIMScheduler:
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
         self.grad_target = grad_target
+        # True (default): every clip of a batch is guided by its own loss / gradient norms, i.e. a batch equals B independent
+        # B = 1 runs (the only case the reference ever ran).  False: the reference's literal whole-tensor norms
+        # (torch.linalg.norm over the batch tensor, scheduling_dps.py:205-206; DSG / DiffMusic norms likewise).
+        self.per_clip_norm = per_clip_norm
         self.last_grad = None
         self.debug_keep_grad = False
 
@@ -108,6 +112,11 @@ class GuidedDDIMScheduler:
         mel = vae.decode_hip(x0, z_scale=zs, keep_state=True)              # (B, H, W) fp16
         wav = vocoder.forward(mel)                                         # (B, Lfull) fp32
         loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space, **(op_kwargs or {}))
+        if not self.per_clip_norm and loss.numel() > 1:
+            # whole-batch norm: L = sqrt(sum_b L_b^2), dL/dwav_b = (L_b / L) * dL_b/dwav_b  (device-side, B scalars)
+            total = torch.linalg.vector_norm(loss)
+            dwav.mul_((loss / total.clamp_min(1e-30))[:, None])
+            loss = total.reshape(1)
         inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
         L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
                 "grad_normalize")
@@ -158,7 +167,7 @@ class GuidedDDIMScheduler:
         x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
         grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
         L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out), _p(grad_out),
-                                   B, n, a_t, a_p, sigma, float(rate), float(eps), 0, _stream()), "sched_step")
+                                   B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1, _stream()), "sched_step")
         self.last_grad = grad_out
         if loss.numel() == 1 and self.mode != "ddim":
             loss = loss.reshape(())

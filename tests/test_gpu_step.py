@@ -69,6 +69,18 @@ CASES = [("dps", "music_inpainting", 0.0, 5e-4, "mel_spectrogram", 501), ("dps",
 
 @pytest.mark.parametrize("name,task,eta,rate,space,t", CASES)
 def test_teacher_forced_step(nets, name, task, eta, rate, space, t):
+    _teacher_forced(nets, name, task, eta, rate, space, t, True)
+
+
+@pytest.mark.parametrize("name,task,eta,rate,space,t", [("dps", "music_inpainting", 0.0, 5e-4, "mel_spectrogram", 501),
+                                                        ("dsg", "music_inpainting", 1.0, 0.08, "mel_spectrogram", 501),
+                                                        ("diffmusic", "phase_retrieval", 1.0, 0.08, "mel_spectrogram", 251)])
+def test_teacher_forced_step_whole_batch_norms(nets, name, task, eta, rate, space, t):
+    """per_clip_norm=False: the reference's literal torch.linalg.norm over the whole batch tensor (loss, DSG / DiffMusic norms)."""
+    _teacher_forced(nets, name, task, eta, rate, space, t, False)
+
+
+def _teacher_forced(nets, name, task, eta, rate, space, t, per_clip):
     from diffmusic_amd.schedulers import get_scheduler
     from oracle import schedulers as OS
     voc, vae, rvoc, rvae = nets
@@ -86,10 +98,10 @@ def test_teacher_forced_step(nets, name, task, eta, rate, space, t):
     x = torch.randn(B, 8, H, W, generator=g)
     e = torch.randn(B, 8, H, W, generator=g)
     z = torch.randn(B, 8, H, W, generator=g)
-    sched = get_scheduler(name)(operator=op, **SCHED)
+    sched = get_scheduler(name)(operator=op, per_clip_norm=per_clip, **SCHED)
     sched.set_timesteps(200)
     sched.debug_keep_grad = True
-    rs = OS.get_scheduler(name)(operator=rop, per_clip_norm=True, **SCHED)
+    rs = OS.get_scheduler(name)(operator=rop, per_clip_norm=per_clip, **SCHED)
     rs.set_timesteps(200)
     kw = dict(eta=eta, ip_guidance_rate=rate, original_waveform_length=LEN, supervised_space=space)
     noise_kw = dict(sample_noise=z.cuda()) if name in ("dsg", "diffmusic") else dict(variance_noise=z.cuda() if eta > 0 else None)
