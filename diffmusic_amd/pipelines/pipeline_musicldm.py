@@ -146,7 +146,13 @@ class MusicLDMPipeline:
                  optim_prompt_learning_rate=0.0001, optim_outer_loop=1, show_progress=True, prompt_type=None,
                  supervised_space="mel_spectrogram"):
         if prompt_embeds is None:
-            raise NotImplementedError("the CLAP text encoder is out of scope of this engine: pass prompt_embeds (B, 512)")
+            front = getattr(self, "text_frontend", None)
+            if front is None or prompt is None:
+                raise NotImplementedError("no text front end attached: pass prompt_embeds (B, 512), or set pipe.text_frontend = "
+                                          "ClapTextFrontEnd(...) (diffmusic_amd/pipelines/prompt.py) to use `prompt=`")
+            prompt_embeds, ne = front.encode(prompt, negative_prompt, guidance_scale > 1.0)     # pipeline_musicldm.py:119-250
+            if negative_prompt_embeds is None:
+                negative_prompt_embeds = ne
         if optim_prompt:
             raise NotImplementedError("optim_prompt is a no-op in the reference and disabled in every config")
         vcfg = self.vocoder.config

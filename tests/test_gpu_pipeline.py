@@ -100,3 +100,48 @@ def test_example_driver_end_to_end(tmp_path):
     out = tmp_path / "musicldm" / "moises" / "dps" / "music_inpainting"
     for d in ("wav_input", "wav_recon", "wav_label", "mel_recon"):
         assert len(list((out / d).iterdir())) == 2
+
+
+def test_pipeline_accepts_prompt_through_text_frontend():
+    """`pipe(prompt=...)` with a text front end attached (diffmusic_amd/pipelines/prompt.py) equals passing its embeddings."""
+    import torch
+    from types import SimpleNamespace
+    from diffmusic_amd.pipelines import get_pipeline
+    from diffmusic_amd.pipelines.prompt import ClapTextFrontEnd
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd import inverse_problem as P
+
+    class Tok:
+        model_max_length = 8
+
+        def __call__(self, texts, padding=None, max_length=None, truncation=False, return_tensors=None):
+            n = max_length if padding == "max_length" else max(1, max(len(t) for t in texts))
+            ids = torch.zeros(len(texts), n, dtype=torch.long)
+            mask = torch.zeros(len(texts), n, dtype=torch.long)
+            for i, t in enumerate(texts):
+                r = [1 + (ord(c) % 50) for c in t][:n]
+                ids[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+                mask[i, :len(r)] = 1
+            return SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+        def batch_decode(self, ids):
+            return [""] * len(ids)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(0)
+            self.emb = torch.nn.Embedding(64, 512)
+
+        def get_text_features(self, ids, attention_mask=None):
+            return torch.nn.functional.normalize((self.emb(ids) * attention_mask[..., None]).sum(1) + 1e-3, dim=-1)
+
+    pipe = get_pipeline("musicldm").from_pretrained("synthetic", seed=0).to("cuda")
+    pipe.scheduler = get_scheduler("ddim")(operator=P.IdentityOperator(16000), **SCHED)
+    front = ClapTextFrontEnd(Enc(), Tok())
+    pe, ne = front.encode(["soft piano"], None, True)
+    kw = dict(num_inference_steps=2, audio_length_in_s=0.64, guidance_scale=2.0, show_progress=False, output_type="latent")
+    a = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, generator=torch.Generator().manual_seed(5), **kw).audios
+    pipe.text_frontend = front
+    b = pipe(prompt=["soft piano"], generator=torch.Generator().manual_seed(5), **kw).audios
+    assert torch.equal(a, b)

@@ -103,3 +103,50 @@ def test_example_driver_host_side():
         clips = mod.load_clips([path], 2, 16000, 8000, 0)
     assert clips.shape == (2, 8000) and float(clips.abs().max()) <= 1.0
     assert float(clips[0, 4000:].abs().max()) == 0.0            # short file zero-padded to the clip length
+
+
+def test_clap_text_frontend_glue():
+    """diffmusic_amd/pipelines/prompt.py against the rules of MusicLDMPipeline._encode_prompt (pipeline_musicldm.py:119-250)
+    with a stand-in tokenizer / encoder (duck-typed like transformers' objects)."""
+    import pytest
+    import torch
+    from types import SimpleNamespace
+    from diffmusic_amd.pipelines.prompt import ClapTextFrontEnd
+
+    class Tok:
+        model_max_length = 6
+
+        def __call__(self, texts, padding=None, max_length=None, truncation=False, return_tensors=None):
+            rows = [[1 + (ord(c) % 50) for c in t] for t in texts]
+            n = max_length if padding == "max_length" else max(1, max(len(r) for r in rows))
+            ids = torch.zeros(len(rows), n, dtype=torch.long)
+            mask = torch.zeros(len(rows), n, dtype=torch.long)
+            for i, r in enumerate(rows):
+                r = r[:n] if truncation or padding == "max_length" else r
+                ids[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+                mask[i, :len(r)] = 1
+            return SimpleNamespace(input_ids=ids, attention_mask=mask)
+
+        def batch_decode(self, ids):
+            return ["?"] * len(ids)
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.emb = torch.nn.Embedding(64, 512)
+
+        def get_text_features(self, ids, attention_mask=None):
+            e = (self.emb(ids) * attention_mask[..., None]).sum(1)
+            return torch.nn.functional.normalize(e + 1e-3, dim=-1)
+
+    front = ClapTextFrontEnd(Enc(), Tok())
+    pe, ne = front.encode(["piano", "drums and bass"], None, True)
+    assert pe.shape == (2, 512) and ne.shape == (2, 512)
+    assert torch.allclose(ne[0], ne[1])                       # negative prompt defaults to "" for every item
+    pe1, ne1 = front.encode("piano", "noise", True)
+    assert pe1.shape == (1, 512) and torch.allclose(pe1[0], pe[0])
+    assert front.encode("piano", None, False)[1] is None
+    with pytest.raises(ValueError):
+        front.encode(["a", "b"], ["x"], True)
+    with pytest.raises(TypeError):
+        front.encode(["a", "b"], "x", True)
