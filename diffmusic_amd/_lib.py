@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
                 ("sCo", C.c_longlong), ("sCi", C.c_longlong),
                 ("alpha", C.c_float), ("act_slope", C.c_float), ("mask_slope", C.c_float),
                 ("flags", C.c_int),
-                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int)]
+                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ksplit", C.c_int)]
 
 
 EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV = \
@@ -87,6 +87,7 @@ _SIGS = {
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "dmx_flash_attn_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p]),
+    "dmx_gemm_splitk_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dmx_conv_pair_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),

@@ -122,4 +122,9 @@ int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, co
   return rc;
 }
 
+int dmx_gemm_splitk_workspace(void* ws, size_t bytes) {
+  dmx_gemm_set_splitk_workspace(reinterpret_cast<float*>(ws), ws ? bytes : 0);
+  return DMX_OK;
+}
+
 }  // extern "C"

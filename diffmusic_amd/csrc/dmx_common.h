@@ -113,7 +113,9 @@ struct GemmDesc {
   signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
   float resid_inv_slope;
   int tile_cfg;          // 0 = automatic; 1..6 force a tile configuration (tuning hook)
+  int ksplit;            // internal: > 1 = this launch is one K slice per blockIdx.z writing fp32 partials (set by the dispatcher)
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);
+void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes);
 bool dmx_prof_is_active();

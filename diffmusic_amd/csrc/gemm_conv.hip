@@ -197,7 +197,8 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int zo = z / p.Zi, zi = z - zo * p.Zi;
   const act_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
   const act_t* Wb = p.W + zo * p.sWo + zi * p.sWi;
-  const long long coff = zo * p.sCo + zi * p.sCi;
+  const int nsplit = p.ksplit > 1 ? p.ksplit : 1, sp = blockIdx.z;     // split-K: this workgroup owns K steps [ks0, ks1)
+  const long long coff = zo * p.sCo + zi * p.sCi + (nsplit > 1 ? (long long)sp * p.M * p.N : 0ll);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, NUMREC, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, NUMREC, 0x00020000);
 
@@ -234,7 +235,11 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // input rows of a channel group are re-read from L2 by consecutive K-steps instead of once per pass over all channels
   const bool tap_inner = (p.Ci & 63) == 0 && p.ntaps > 1;
   const int cgroups = p.Ci >> 6;
-  auto issue = [&](int ks, int stage) {
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int ks_per = (nk_all + nsplit - 1) / nsplit;
+  const int ks0 = sp * ks_per, ks1 = ks0 + ks_per < nk_all ? ks0 + ks_per : nk_all;
+  auto issue = [&](int ksl, int stage) {
+    const int ks = ksl + ks0;
     int kc;
     if (tap_inner) {
       const int cg = ks / p.ntaps, tp = ks - cg * p.ntaps;
@@ -244,7 +249,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     }
     const int tap = kc / cpt;
     const unsigned cin2 = (unsigned)(kc - tap * cpt) << 4;      // byte offset of the chunk inside the pixel
-    const bool kval = kc < kchunks;
+    const bool kval = kc < kchunks && ks < ks1;
     const short2 t = s_taps[tap & (DMX_MAX_TAPS - 1)];
     char* sbase = smem + stage * STAGE;
 #pragma unroll
@@ -272,7 +277,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // NSTAGE-deep ring: tiles ks+1 .. ks+NSTAGE-1 are in flight while tile ks is consumed.  Every iteration issues
   // exactly one stage (past the end the offsets are out of range -> zero fill, no memory traffic), so the vmcnt
   // counts are compile-time constants; the raw s_barrier keeps the younger loads in flight across it.
-  const int nk = (p.K + BK - 1) / BK;
+  const int nk = ks1 > ks0 ? ks1 - ks0 : 0;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
@@ -436,7 +441,7 @@ int launch_glds(const GemmDesc& d, hipStream_t stream) {
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
-  dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
+  dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
   hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
@@ -618,6 +623,95 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
   return n;
 }
 
+// ---- split-K for small-M / deep-K convolutions (the low-resolution U-Net levels: M = 1024, K = 5760 is 160 tiles of 90
+// serial K steps): the K range is cut into `ksplit` slices that run as extra workgroups (blockIdx.z) and write fp32 partial
+// tiles; this kernel adds the slices and applies the whole fused epilogue.
+namespace {
+float* g_splitk_ws = nullptr;
+size_t g_splitk_bytes = 0;
+
+__global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict__ ws, int ksplit) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 4 consecutive channels
+  const int nq = p.N >> 2;
+  if (q >= (long long)p.M * nq) return;
+  const int m = (int)(q / nq), n = (int)(q - (long long)m * nq) * 4;
+  const long long mn = (long long)p.M * p.N;
+  float4 v = *reinterpret_cast<const float4*>(ws + (long long)m * p.N + n);
+  for (int s = 1; s < ksplit; ++s) {
+    const float4 w = *reinterpret_cast<const float4*>(ws + s * mn + (long long)m * p.N + n);
+    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+  }
+  float a[4] = {v.x, v.y, v.z, v.w};
+  const int flags = p.flags;
+  const long long row = m;                                                   // identity row map (checked by the dispatcher)
+  if (flags & EPI_MASK) {
+    const uint2 xr = *reinterpret_cast<const uint2*>(p.X + row * p.ldx + n);
+    const float x[4] = {alo(xr.x), ahi(xr.x), alo(xr.y), ahi(xr.y)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] *= x[e] > 0.f ? 1.f : p.mask_slope;
+  }
+  if (flags & EPI_BIAS) {
+    const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+    a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+  }
+  if (flags & EPI_ROWBIAS) {
+    const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)(m / (p.Hq * p.Wq)) * p.N + n);
+    a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
+  }
+  if (flags & EPI_RESID) {
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.R + row * p.ldr + n);
+    const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
+    const float x[4] = {alo(rr.x), ahi(rr.x), alo(rr.y), ahi(rr.y)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += fminf(x[e], x[e] * is);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a[e] *= p.alpha;
+  if (!(flags & EPI_NO_C))
+    *reinterpret_cast<uint2*>(reinterpret_cast<act_t*>(p.C) + row * p.ldc + n) = make_uint2(pack2a(a[0], a[1]), pack2a(a[2], a[3]));
+  if (flags & EPI_LRELU2) {
+    const float sl = p.act_slope;
+    *reinterpret_cast<uint2*>(p.C2 + row * p.ldc2 + n) =
+        make_uint2(pack2a(fmaxf(a[0], a[0] * sl), fmaxf(a[1], a[1] * sl)), pack2a(fmaxf(a[2], a[2] * sl), fmaxf(a[3], a[3] * sl)));
+  }
+}
+
+// returns the number of K slices to use for `d` (1 = no split)
+int splitk_plan(const GemmDesc& d) {
+  static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
+  if (off || !g_splitk_ws || d.Z != 1 || d.tile_cfg || !glds_ok(d)) return 1;
+  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH)) return 1;
+  if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
+  if ((d.N & 7) || (d.ldc & 3) || d.M > 8192) return 1;
+  const int nk = (d.K + BK - 1) / BK;
+  const long long tiles = (long long)cdiv(d.M, 64) * cdiv(d.N, 64);
+  if (nk < 24 || tiles >= 512) return 1;
+  int ks = (int)(1024 / tiles);                 // aim at ~4 workgroups per CU
+  if (ks > nk / 8) ks = nk / 8;                 // at least 8 K steps per slice
+  if (ks > 8) ks = 8;
+  while (ks > 1 && (size_t)ks * d.M * d.N * sizeof(float) > g_splitk_bytes) --ks;
+  return ks < 2 ? 1 : ks;
+}
+
+int launch_splitk(const GemmDesc& d, int ks, hipStream_t stream) {
+  GemmDesc g = d;
+  g.ksplit = ks;
+  g.flags = EPI_F32OUT;
+  g.C = g_splitk_ws; g.C2 = nullptr; g.ldc = d.N; g.alpha = 1.f;
+  g.bias = nullptr; g.rowbias = nullptr; g.R = nullptr; g.X = nullptr;
+  g.Ho = d.Hq; g.Wo = d.Wq;
+  int rc = launch_by_cfg(d.N % 128 == 0 && d.M >= 4096 ? 14 : 12, g, stream);
+  if (rc != DMX_OK) return rc;
+  const long long nthr = (long long)d.M * (d.N >> 2);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, d, g_splitk_ws, ks);
+  g_last_cfg = 40 + ks;
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+}  // namespace
+
+// fp32 scratch for split-K partial tiles (owned by the caller, e.g. a model; stream-ordered use only)
+void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes) { g_splitk_ws = ws; g_splitk_bytes = bytes; }
+
 int dmx_prof_open(hipStream_t st) {
   if (!g_prof) return -1;
   ProfRec r;
@@ -642,7 +736,8 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   // the LDS epilogue evaluates leaky-relu as max(v, v*slope) and the inverse as min(x, x/slope)
   if ((d.flags & EPI_LRELU2) && !(d.act_slope >= 0.f && d.act_slope <= 1.f)) return DMX_ERR_SHAPE;
   if ((d.flags & EPI_RESID_INV) && !(d.resid_inv_slope >= 1.f)) return DMX_ERR_SHAPE;
-  if (!g_prof) return launch_dispatch(d, stream);
+  const int ksp = splitk_plan(d);
+  if (!g_prof) return ksp > 1 ? launch_splitk(d, ksp, stream) : launch_dispatch(d, stream);
   ProfRec r;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
   r.flops = 2.0 * d.M * (double)d.N * d.K * d.Z;
@@ -658,7 +753,7 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   }
   r.M = d.M; r.N = d.N; r.K = d.K; r.Z = d.Z; r.taps = d.ntaps; r.flags = d.flags;
   (void)hipEventRecord(r.a, stream);
-  const int rc = launch_dispatch(d, stream);
+  const int rc = ksp > 1 ? launch_splitk(d, ksp, stream) : launch_dispatch(d, stream);
   (void)hipEventRecord(r.b, stream);
   r.cfg = g_last_cfg;
   g_prof_recs.push_back(r);

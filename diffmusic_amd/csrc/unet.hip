@@ -220,7 +220,11 @@ struct UNet : Model {
     norm_out.build(ps, "conv_norm_out", boc[0], G, 1e-5f);
     conv_out = make_conv2d(ps, "conv_out", boc[0], c.out_channels, 3, 1, 1, false);
     gn_partial = (float*)ps.dalloc(dmx_gn_scratch_floats(64, 2048, G) * sizeof(float));
+    splitk_ws = (float*)ps.dalloc(kSplitKBytes);        // fp32 partial tiles of the split-K low-resolution convolutions
   }
+
+  static constexpr size_t kSplitKBytes = 64u << 20;
+  float* splitk_ws = nullptr;
 
   int finalize(hipStream_t st) override {
     CTRY(pack_layer(ps, time1, st)); CTRY(pack_layer(ps, time2, st));
@@ -259,6 +263,7 @@ struct UNet : Model {
     if (B > 64) { dmx_set_error("unet: batch > 64 unsupported"); return DMX_ERR_SHAPE; }
     dry = (ws == nullptr);
     arena.reset(ws, dry ? (size_t)-1 : wsb);
+    if (!dry) dmx_gemm_set_splitk_workspace(splitk_ws, splitk_ws ? kSplitKBytes : 0);
     Ctx cx{&arena, st, dry, gn_partial};
     Arena& A = arena;
     const int nb = cfg.num_blocks;

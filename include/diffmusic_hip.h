@@ -195,6 +195,9 @@ int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
  * columns past Nk, o (B,Nq,C); colbias optional (B,Nk) fp32 additive key bias. */
 int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, const float* colbias, int B, int Nq, int Nk, int Nkp,
                        int C, int heads, float scale, void* stream);
+/* test hook: fp32 scratch that lets small-M / deep-K launches run split-K (NULL disables it); the U-Net executor
+ * installs its own */
+int dmx_gemm_splitk_workspace(void* ws, size_t bytes);
 int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes, void* stream);
 
 #ifdef __cplusplus

@@ -229,3 +229,32 @@ def test_slab_conv_single_stage():
     _pair_run(L, None, d)
     ref = F.conv1d(x.float().transpose(1, 2), w.float(), bias, padding=(k * dil - dil) // 2, dilation=dil).transpose(1, 2)
     assert _rel(out, ref) < 4e-3
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(16, 8, 8, 640, 640), (4, 16, 16, 384, 384), (16, 8, 8, 1280, 640)])
+def test_split_k_small_m_conv(B, H, W, Ci, Co):
+    """3x3 convolution of a low-resolution U-Net level (M = B*H*W <= 4096, K = 9*Ci): with the split-K scratch installed the
+    launch runs as K slices + a reduce/epilogue kernel; same result as the single-pass kernel and as torch fp32."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B, H, W, Ci, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(_adt()).cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+    bias = torch.randn(Co, generator=g).cuda()
+    rowb = torch.randn(B, Co, generator=g).cuda()
+    res = torch.randn(B, H, W, Co, generator=g).to(_adt()).cuda()
+    outs = []
+    scratch = torch.empty(16 << 20, dtype=torch.float32, device="cuda")
+    for ws in (None, scratch):
+        L.check(L.lib().dmx_gemm_splitk_workspace(C.c_void_p(ws.data_ptr()) if ws is not None else None, ws.numel() * 4 if ws is not None else 0), "ws")
+        out = torch.zeros(B, H, W, Co, dtype=_adt(), device="cuda")
+        d = _desc(L, A=x, W=wp, C=out, bias=bias, rowbias=rowb, R=res, M=B * H * W, N=Co, K=9 * Ci, ldw=9 * Ci, Hi=H, Wi=W, Ci=Ci, lda=Ci,
+                  Hq=H, Wq=W, ntaps=9, Ho=H, Wo=W, ldc=Co, ldr=Co, ldx=Co, ldc2=Co, flags=L.EPI_BIAS | L.EPI_ROWBIAS | L.EPI_RESID,
+                  tdy=[t // 3 - 1 for t in range(9)], tdx=[t % 3 - 1 for t in range(9)])
+        _run(L, d)
+        outs.append(out)
+    L.check(L.lib().dmx_gemm_splitk_workspace(None, 0), "ws")
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1) + rowb[:, None, None, :] + res.float()
+    assert _rel(outs[1], ref) < 3e-3
+    assert _rel(outs[0], ref) < 3e-3
+    assert _rel(outs[1], outs[0]) < 2e-3
