@@ -685,7 +685,7 @@ int splitk_plan(const GemmDesc& d) {
   if ((d.N & 7) || (d.ldc & 3) || d.M > 8192) return 1;
   const int nk = (d.K + BK - 1) / BK;
   const long long tiles = (long long)cdiv(d.M, 64) * cdiv(d.N, 64);
-  if (nk < 24 || tiles >= 512) return 1;
+  if (nk < 24 || tiles >= 256) return 1;        // only when the tile grid cannot fill the 256 CUs (measured: 378 tiles x 2 slices is slower)
   int ks = (int)(1024 / tiles);                 // aim at ~4 workgroups per CU
   if (ks > nk / 8) ks = nk / 8;                 // at least 8 K steps per slice
   if (ks > 8) ks = 8;
