@@ -118,4 +118,5 @@ struct GemmDesc {
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);
 void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes);
+void dmx_gemm_release_splitk_workspace(const float* ws);
 bool dmx_prof_is_active();

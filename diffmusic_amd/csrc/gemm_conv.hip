@@ -711,6 +711,9 @@ int launch_splitk(const GemmDesc& d, int ks, hipStream_t stream) {
 
 // fp32 scratch for split-K partial tiles (owned by the caller, e.g. a model; stream-ordered use only)
 void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes) { g_splitk_ws = ws; g_splitk_bytes = bytes; }
+// the owner is going away: forget the scratch if it is the one installed (a dangling pointer here would be written by the
+// next eligible launch of any model)
+void dmx_gemm_release_splitk_workspace(const float* ws) { if (g_splitk_ws == ws) { g_splitk_ws = nullptr; g_splitk_bytes = 0; } }
 
 int dmx_prof_open(hipStream_t st) {
   if (!g_prof) return -1;

@@ -225,6 +225,7 @@ struct UNet : Model {
 
   static constexpr size_t kSplitKBytes = 64u << 20;
   float* splitk_ws = nullptr;
+  ~UNet() override { dmx_gemm_release_splitk_workspace(splitk_ws); }
 
   int finalize(hipStream_t st) override {
     CTRY(pack_layer(ps, time1, st)); CTRY(pack_layer(ps, time2, st));
