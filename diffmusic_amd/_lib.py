@@ -48,7 +48,7 @@ class GemmDesc(C.Structure):
                 ("sCo", C.c_longlong), ("sCi", C.c_longlong),
                 ("alpha", C.c_float), ("act_slope", C.c_float), ("mask_slope", C.c_float),
                 ("flags", C.c_int),
-                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ksplit", C.c_int)]
+                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ldrb", C.c_int), ("ksplit", C.c_int)]
 
 
 EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV = \

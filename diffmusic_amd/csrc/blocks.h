@@ -74,7 +74,9 @@ struct Resnet2D {
   }
   // x (B,H,W,Cin) -> out (B,H,W,Cout) (caller-allocated).  silu_emb (B, temb_ch) fp16, already SiLU'd.
   // tape != nullptr keeps what backward() needs (persistent arena allocations).
-  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* silu_emb, ResnetTape* tape) const {
+  // rb_pre / ldrb: this block's slice of a time-embedding projection computed for all blocks in one GEMM (U-Net)
+  int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* silu_emb, ResnetTape* tape,
+          const float* rb_pre = nullptr, int ldrb = 0) const {
     Arena& A = *cx.arena;
     const size_t P = (size_t)H * W;
     ResnetTape t;
@@ -85,7 +87,9 @@ struct Resnet2D {
     act_t* n = A.bf(B * P * (Cin > Cout ? Cin : Cout));
     CTRY(norm1.fwd(cx, x, n, B, (int)P, 1, t.g1));
     Epi e1;
-    if (has_temb) {
+    if (has_temb && rb_pre) {
+      e1.flags = EPI_ROWBIAS; e1.rowbias = rb_pre; e1.ldrb = ldrb;
+    } else if (has_temb) {
       float* rb = A.f32((size_t)B * Cout);
       Epi et; et.flags = EPI_F32OUT;
       CRUN(linear_fwd(temb, silu_emb, temb.Cip, rb, Cout, B, et, cx.st));

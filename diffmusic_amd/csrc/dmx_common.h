@@ -113,6 +113,7 @@ struct GemmDesc {
   signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
   float resid_inv_slope;
   int tile_cfg;          // 0 = automatic; 1..6 force a tile configuration (tuning hook)
+  int ldrb;              // row stride of rowbias in floats (0 = N); > N when it is a slice of a batched projection
   int ksplit;            // internal: > 1 = this launch is one K slice per blockIdx.z writing fp32 partials (set by the dispatcher)
 };
 

@@ -655,7 +655,7 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
     a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
   }
   if (flags & EPI_ROWBIAS) {
-    const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)(m / (p.Hq * p.Wq)) * p.N + n);
+    const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)(m / (p.Hq * p.Wq)) * (p.ldrb ? p.ldrb : p.N) + n);
     a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
   }
   if (flags & EPI_RESID) {

@@ -45,7 +45,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
       }
       if (flags & EPI_ROWBIAS) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * p.N + n);
+        const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)b * (p.ldrb ? p.ldrb : p.N) + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
       }
       if (flags & EPI_RESID) {
@@ -278,7 +278,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
           if (flags & EPI_ROWBIAS) {
-            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)bimg * p.N + n);
+            const float4 bb = *reinterpret_cast<const float4*>(p.rowbias + (long long)bimg * (p.ldrb ? p.ldrb : p.N) + n);
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
         }

@@ -74,6 +74,7 @@ struct Epi {
   const act_t* X = nullptr;
   act_t* C2 = nullptr;
   const float* rowbias = nullptr;
+  int ldrb = 0;                 // row stride of rowbias (0 = the layer's padded Cout)
 };
 
 // registry helpers

@@ -158,7 +158,7 @@ static void init_desc(GemmDesc& d, const Epi& e) {
   d.sy = d.sx = 1; d.osy = d.osx = 1;
   d.alpha = e.alpha; d.act_slope = e.act_slope; d.mask_slope = e.mask_slope; d.resid_inv_slope = e.resid_inv_slope;
   d.flags = e.flags;
-  d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias;
+  d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias; d.ldrb = e.ldrb;
 }
 static void set_out(GemmDesc& d, void* C, int Ho, int Wo, int ldc) {
   d.C = C; d.Ho = Ho; d.Wo = Wo; d.ldc = d.ldr = d.ldx = d.ldc2 = ldc;

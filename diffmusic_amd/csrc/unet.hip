@@ -225,6 +225,13 @@ struct UNet : Model {
 
   static constexpr size_t kSplitKBytes = 64u << 20;
   float* splitk_ws = nullptr;
+  // every resnet's time_emb_proj stacked along N: one (B x temb_ch) x (sum Cout) GEMM per forward instead of 22 M = 16 launches
+  ConvLayer temb_all;
+  std::vector<const Resnet2D*> temb_order;
+  std::vector<int> temb_off;
+  int temb_total = 0;
+  bool temb_fused = false;
+  int temb_slot(const Resnet2D* r) const { for (size_t i = 0; i < temb_order.size(); ++i) if (temb_order[i] == r) return temb_off[i]; return -1; }
   ~UNet() override { dmx_gemm_release_splitk_workspace(splitk_ws); }
 
   int finalize(hipStream_t st) override {
@@ -240,6 +247,35 @@ struct UNet : Model {
       }
     CTRY(mid_r0.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
     for (auto& a : mid_attns) CTRY(a.pack(ps, st));
+    // fused time-embedding projection
+    temb_order.clear(); temb_off.clear(); temb_total = 0;
+    for (auto& b : down) for (auto& r : b.res) if (r.has_temb) temb_order.push_back(&r);
+    if (mid_r0.has_temb) temb_order.push_back(&mid_r0);
+    if (mid_r1.has_temb) temb_order.push_back(&mid_r1);
+    for (auto& b : up) for (auto& r : b.res) if (r.has_temb) temb_order.push_back(&r);
+    for (const Resnet2D* r : temb_order) { temb_off.push_back(temb_total); temb_total += r->temb.Cop; }
+    temb_fused = false;
+    if (!temb_order.empty() && getenv("DMX_NO_TEMB_FUSE") == nullptr) {
+      const int Cip = temb_order[0]->temb.Cip;
+      act_t* w = (act_t*)ps.dalloc((size_t)temb_total * Cip * sizeof(act_t));
+      float* bsum = (float*)ps.dalloc((size_t)temb_total * sizeof(float));
+      if (!w || !bsum) return DMX_ERR_PARAM;
+      bool ok = true;
+      for (size_t i = 0; i < temb_order.size(); ++i) {
+        const ConvLayer& L = temb_order[i]->temb;
+        if (L.Cip != Cip) { ok = false; break; }
+        (void)hipMemcpyAsync(w + (size_t)temb_off[i] * Cip, L.wf[0], (size_t)L.Cop * Cip * sizeof(act_t), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(bsum + temb_off[i], L.bias, (size_t)L.Cop * sizeof(float), hipMemcpyDeviceToDevice, st);
+      }
+      if (ok) {
+        temb_all = temb_order[0]->temb;
+        temb_all.Co = temb_all.Cop = temb_total;
+        temb_all.wf.assign(1, w);
+        temb_all.bias = bsum;
+        temb_all.has_bias = true;
+        temb_fused = true;
+      }
+    }
     return DMX_OK;
   }
 
@@ -303,6 +339,13 @@ struct UNet : Model {
       CRUN(dmx_silu(emb, semb, (long long)B * temb_ch, st));
       A.release(mk);
     }
+    float* rb_all = nullptr;
+    if (temb_fused) {
+      rb_all = A.f32((size_t)B * temb_total);
+      Epi et; et.flags = EPI_F32OUT;
+      CRUN(linear_fwd(temb_all, semb, temb_all.Cip, rb_all, temb_total, B, et, st));
+    }
+    auto rb_of = [&](const Resnet2D& r) -> const float* { const int o = temb_fused ? temb_slot(&r) : -1; return o >= 0 ? rb_all + o : nullptr; };
     // ---- input conv
     int H = H0, W = W0;
     std::vector<Skip> skips;
@@ -324,10 +367,10 @@ struct UNet : Model {
         if (b.has_attn) {
           act_t* y2 = A.bf((size_t)B * H * W * b.ch);   // resnet output (transient but simpler to keep)
           act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * b.ch) : nullptr;
-          CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr));
+          CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
           CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
         } else {
-          CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr));
+          CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
         }
         cur = y;
         skips.push_back({cur, H, W, b.ch});
@@ -347,9 +390,9 @@ struct UNet : Model {
       act_t* y1 = A.bf((size_t)B * H * W * cm);
       act_t* y2 = A.bf((size_t)B * H * W * cm);
       act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * cm) : nullptr;
-      CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr));
+      CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr, rb_of(mid_r0), temb_total));
       CTRY(run_attn(cx, mid_attns.data(), y0, y1, y3, B, H, W));
-      CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr));
+      CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr, rb_of(mid_r1), temb_total));
       cur = y2;
     }
     // ---- up
@@ -369,10 +412,10 @@ struct UNet : Model {
         CRUN(dmx_copy_channels(cur, cat, (long long)B * H * W, curC, curC, cc, 0, 0, st));
         CRUN(dmx_copy_channels(s.p, cat, (long long)B * H * W, s.C, s.C, cc, 0, curC, st));
         if (b.has_attn) {
-          CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr));
+          CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
           CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
         } else {
-          CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr));
+          CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
         }
         A.release(mk);
         cur = y; curC = b.ch;
