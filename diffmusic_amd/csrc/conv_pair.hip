@@ -232,6 +232,10 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
     Frags fa, fb;
     load_frags(fa, isB, 0, g0);
     pair_settle(fa);
+    // the first step below re-fills ring tile g0 % NS (weights of step g0 + 3) right away: every wave must have taken its step-g0
+    // fragments out of it first.  (Inside the loop the end-of-step barrier gives this guarantee; without this one ~2 % of the
+    // outputs changed from run to run.)
+    __builtin_amdgcn_s_barrier();
     for (int sidx = 0; sidx < n; sidx += 2) {
       step(fa, fb, isB, sidx, n, g0 + sidx);
       if (sidx + 1 < n) step(fb, fa, isB, sidx + 1, n, g0 + sidx + 1);
@@ -253,6 +257,9 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
 #pragma unroll
         for (int n = 0; n < FN; ++n)
           rpre[i * FN + n] = *reinterpret_cast<const uint2*>(slab + (rg * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (cg * 64 + n * 16 + lq * 4) * 2);
+      // these rows reach loA + loB rows into the NEXT row group's region, which that group's waves overwrite below:
+      // everybody must have taken its residual before anybody stores the intermediate
+      __syncthreads();
     }
     // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
     const int fa = P.a.flags;
