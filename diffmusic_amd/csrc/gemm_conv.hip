@@ -516,10 +516,12 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 12: return launch_glds<64, 64, 2, 2, 4>(d, stream);
     case 13: return launch_glds<128, 64, 2, 2, 3>(d, stream);
     case 14: return launch_glds<64, 128, 2, 2, 3>(d, stream);
-    case 15: return launch_glds_mixed<320, 192, 256, 2, 4, 2>(d, stream);   // alternating tile heights: desynchronised epilogues
+#ifdef DMX_MIXED_TILES      // experiment (measured slower): two tile heights in one launch
+    case 15: return launch_glds_mixed<320, 192, 256, 2, 4, 2>(d, stream);
     case 16: return launch_glds_mixed<320, 192, 128, 4, 2, 2>(d, stream);
     case 17: return launch_glds_mixed<320, 256, 256, 2, 4, 2>(d, stream);
     case 18: return launch_glds_mixed<256, 192, 256, 2, 4, 2>(d, stream);
+#endif
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);

@@ -104,7 +104,7 @@ def test_batched_nt_gemm_f32_out_and_mask():
     assert _rel(outb, ref) < 6e-3
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_forced_tile_configs_agree(cfg):
     """every tile configuration (incl. the 320x256 LDS-DMA tile) gives the same conv result"""
     from diffmusic_amd import _lib as L
