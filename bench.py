@@ -148,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nan-check", action="store_true", help="skip the per-step host-side NaN test of the loss (the reference loop has it)")
     ap.add_argument("--workload", default="dps_inpainting", choices=sorted(WORKLOADS),
                     help="default = the headline config (BASELINE.json configs[1]); the others are the remaining GPU configs")
     args = ap.parse_args()
@@ -180,8 +181,11 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     loss = None
+    nan_steps = 0
     for _ in range(args.steps):
         latents, loss = one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+        if not args.no_nan_check:            # the loop body's NaN test (pipeline_musicldm.py:741-742): one host sync per step
+            nan_steps += int(bool(torch.isnan(loss).any()))
         k += 1
     ev1.record()
     barrier()
@@ -233,7 +237,7 @@ def main():
                                                                         f"200-step schedule, {WORKLOADS[wl][6]}"),
                           "global_batch": B * world, "clips_per_gpu": B,
                           "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world}",
-                          "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite,
+                          "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_check_per_step": not args.no_nan_check,
                           "final_loss_clip0": float(loss.reshape(-1)[0])},
                "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting":
