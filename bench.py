@@ -5,15 +5,22 @@ over the batch: U-Net on the 2B CFG batch -> CFG combine -> DPSScheduler.step (x
 HiFi-GAN, mask, log-mel, L2, hand-written backward sweep, fused update).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a launcher: this process starts N rank processes itself (fresh children, started before
+anything here touches the GPU), one per device, RCCL rendezvous on 127.0.0.1, and exits with the worst
+child exit code.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks are the launcher's; a world size that differs from --gpus is an error (exit 3).
 
 Prints ONE JSON line on rank 0.  Weights are seeded synthetic (no checkpoints offline), clips are
 synthetic sums of sinusoids; inputs are resident in HBM before the timed region.
+After the timed loop the final latents are decoded and the (B, 160000) waveforms of all ranks are
+all-gathered once (the path's only collective); its time is reported next to the loop's.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -29,6 +36,8 @@ SCHED_CFG = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, b
 SR, SECONDS, N_STEPS, ZETA, GUIDANCE_SCALE = 16000, 10, 200, 5e-4, 2.0
 ALGO_TFLOP_PER_CLIP_STEP = 3.52        # BASELINE.md section 2 (U-Net 2x fwd + VAE fwd/dgrad + HiFi-GAN fwd/dgrad)
 PEAK_TFLOPS_16BIT = 2500.0             # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBPS = 8000.0                 # HBM3E (MI355X_MICROARCH.md)
+MEL_PATH_BYTES_PER_CLIP_STEP = 2.4e6   # fused-ideal fp32 traffic of STFT + mel + loss, forward + backward
 
 
 def synth_clip(k, length):
@@ -47,7 +56,9 @@ WORKLOADS = {
     "dps_inpainting": ("musicldm", "dps", 0.0, 5e-4, "music_inpainting", 8, "configs[1]"),
     "dsg_phase_audioldm2": ("audioldm2", "dsg", 1.0, 0.08, "phase_retrieval", 4, "configs[2] (4 clips per GPU)"),
     "mpgd_sr4": ("musicldm", "mpgd", 0.0, 5e-3, "super_resolution", 4, "configs[3] (4 clips per GPU)"),
+    "diffmusic_style_audioldm2": ("audioldm2", "diffmusic", 1.0, 0.08, "style_guidance", 8, "configs[4] (500-step schedule)"),
 }
+WORKLOAD_STEPS = {"diffmusic_style_audioldm2": 500}
 
 
 def build_problem(B, rank, device, workload="dps_inpainting"):
@@ -62,10 +73,12 @@ def build_problem(B, rank, device, workload="dps_inpainting"):
         op = P.MusicInpaintingOperator(SECONDS, SR, "box", 2, 3, 0.3, 0.1, 1.0, noiser=noiser)
     elif task == "phase_retrieval":
         op = P.PhaseRetrievalOperator(noiser=noiser)
+    elif task == "style_guidance":
+        op = P.StyleGuidanceOperator(SR, noiser=noiser, device=device)
     else:
         op = P.SuperResolutionOperator(SR, 4, noiser=noiser)
     pipe.scheduler = get_scheduler(sname)(operator=op, **SCHED_CFG)
-    pipe.scheduler.set_timesteps(N_STEPS, device=device)
+    pipe.scheduler.set_timesteps(WORKLOAD_STEPS.get(workload, N_STEPS), device=device)
     L = SECONDS * SR
     clips = torch.stack([synth_clip(rank * B + i, L) for i in range(B)]).to(device)
     measurement = op.forward(clips)
@@ -95,8 +108,20 @@ def one_step(pipe, latents, t, cond, measurement, L):
     return out.prev_sample, out.loss
 
 
-def cpu_baseline(seed_sd, threads):
-    """The CPU restatement (oracle/, fp32 eager torch + autograd) timed on the host cores: 1 clip x 1 DPS step."""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(seed_sd, threads, batch):
+    """The CPU restatement (oracle/, fp32 eager torch + autograd) timed on the host cores: `batch` clips, DPS steps.
+    Returns seconds per (batch-`batch`) step: 1 warm-up + 3 measured at batch 1, one measured step at larger batches."""
     from oracle import models as OM, operators as OO, schedulers as OS
     torch.set_num_threads(threads)
     unet, vae, voc = OM.UNetMusicLDM().eval(), OM.VaeDecoder().eval(), OM.HifiGan().eval()
@@ -107,38 +132,72 @@ def cpu_baseline(seed_sd, threads):
     sched = OS.DPSScheduler(operator=op, **SCHED_CFG)
     sched.set_timesteps(N_STEPS)
     L = SECONDS * SR
-    y = op.forward(synth_clip(0, L)[None])
-    x = torch.randn(1, 8, 250, 16, generator=torch.Generator().manual_seed(0))
-    pe = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(7)), dim=-1)
+    y = op.forward(torch.stack([synth_clip(i, L) for i in range(batch)]))
+    x = torch.cat([torch.randn(1, 8, 250, 16, generator=torch.Generator().manual_seed(i)) for i in range(batch)])
+    pe = torch.nn.functional.normalize(torch.randn(batch, 512, generator=torch.Generator().manual_seed(7)), dim=-1)
     ts = [int(t) for t in sched.timesteps]
-    n_meas, t0 = 3, None
-    for i in range(1 + n_meas):                  # 1 warm-up + 3 measured steps
-        if i == 1:
+    n_warm, n_meas = (1, 3) if batch == 1 else (0, 1)
+    t0 = time.perf_counter()
+    for i in range(n_warm + n_meas):
+        if i == n_warm:
             t0 = time.perf_counter()
         with torch.no_grad():
             e2 = unet(torch.cat([x, x]), ts[i], class_labels=torch.cat([pe, pe]))[0]
-        e = e2[:1] + GUIDANCE_SCALE * (e2[1:] - e2[:1])
+        e = e2[:batch] + GUIDANCE_SCALE * (e2[batch:] - e2[:batch])
         x = sched.step(e, ts[i], x, eta=0.0, measurement=y, vae=vae, vocoder=voc, original_waveform_length=L,
                        ip_guidance_rate=ZETA, supervised_space="mel_spectrogram").prev_sample
     return (time.perf_counter() - t0) / n_meas
 
 
 def pmc_traffic(prefix):
-    """HBM-side bytes per launch of one kernel family (its 8-wave tiles, >= 192 rows) from the committed counter passes
-    (profiles/r01_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate `rocprofv3 --pmc` runs of this same command,
-    KiB -> bytes, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be read from inside the process."""
+    """HBM-side bytes per launch of one kernel family (its 8-wave tiles, >= 192 rows) from the newest committed counter passes
+    (profiles/rNN_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv: separate `rocprofv3 --pmc` runs of this same command,
+    KiB -> bytes, FETCH_SIZE doubled per the gfx950 correction).  Counters cannot be read from inside the process, so this
+    is the measurement of the profiled run named in `traffic_source`, not of this run."""
     import csv
-    tot, n = 0.0, 0
+    import glob
     here = os.path.dirname(os.path.abspath(__file__))
+    tags = sorted({os.path.basename(p).split("_pmc_")[0] for p in glob.glob(os.path.join(here, "profiles", "r*_pmc_FETCH_SIZE_per_kernel.csv"))})
+    if not tags:
+        return None, None
+    tag = tags[-1]
+    tot, n = 0.0, 0
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            with open(os.path.join(here, "profiles", f"r01_pmc_{c}_per_kernel.csv")) as fh:
+            with open(os.path.join(here, "profiles", f"{tag}_pmc_{c}_per_kernel.csv")) as fh:
                 rows = [r for r in csv.DictReader(fh) if r["kernel"].startswith(prefix + "<") and int(r["kernel"].split("<")[1].split(",")[0]) >= 192]
             tot += sum(float(r[f"{c}_bytes_total"]) for r in rows)
             n = sum(int(r["launches"]) for r in rows)
     except (OSError, KeyError):
         return None, None
-    return (round(tot / n) if n else None), "profiles/r01_pmc_{FETCH,WRITE}_SIZE_per_kernel.csv (rocprofv3 --pmc, separate passes)"
+    src = f"profiles/{tag}_pmc_{{FETCH,WRITE}}_SIZE_per_kernel.csv (rocprofv3 --pmc, separate passes of `python bench.py`"
+    meta = os.path.join(here, "profiles", f"{tag}_pmc_meta.json")
+    if os.path.exists(meta):
+        with open(meta) as fh:
+            src += ", source tree " + json.load(fh).get("source_sha16", "?")
+    return (round(tot / n) if n else None), src + ")"
+
+
+def spawn_ranks(n, argv, need_gpus):
+    """--gpus N without a launcher: N fresh rank processes (this parent never touches the GPU), RCCL rendezvous on 127.0.0.1."""
+    import socket
+    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
+    if have < need_gpus:
+        print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), DMX_BENCH_SPAWNED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f"[bench] ranks failed: {bad}", file=sys.stderr)
+    return max(abs(rc) for rc in rcs) if bad else 0
 
 
 def main():
@@ -148,33 +207,56 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the second CPU leg (0 = 8 if host memory allows, else 4 / 2 / none)")
     ap.add_argument("--no-nan-check", action="store_true", help="skip the per-step host-side NaN test of the loss (the reference loop has it)")
+    ap.add_argument("--no-stage-times", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="run the U-Net as individual launches instead of the captured HIP graph")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo only to rehearse the "
+                    "multi-rank path on a box with fewer GPUs than ranks (with --share-gpu)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (gloo backend only)")
     ap.add_argument("--workload", default="dps_inpainting", choices=sorted(WORKLOADS),
                     help="default = the headline config (BASELINE.json configs[1]); the others are the remaining GPU configs")
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world == 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], 1 if args.share_gpu else args.gpus))
+    world, rank, local = env_world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(3)
+    import torch.distributed as dist
+    if args.share_gpu:
+        if args.backend != "gloo":
+            print("[bench] --share-gpu is a rehearsal mode and needs --backend gloo (RCCL wants one device per rank)", file=sys.stderr)
+            sys.exit(3)
+        local = 0
     if world > 1:
-        import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
+        if dist.get_world_size() != args.gpus:
+            print(f"[bench] only {dist.get_world_size()} of {args.gpus} ranks joined", file=sys.stderr)
+            sys.exit(3)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     wl = args.workload
     B = args.batch if wl == "dps_inpainting" else WORKLOADS[wl][5]
+    n_sched = WORKLOAD_STEPS.get(wl, N_STEPS)
     pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device, wl)
+    if args.no_graph and hasattr(pipe.unet, "use_graph"):
+        pipe.unet.use_graph = False
     ts = pipe.scheduler._timesteps_host
 
     def barrier():
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     k = 0
     for _ in range(args.warmup):
-        latents, _ = one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+        latents, _ = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
         k += 1
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -183,7 +265,7 @@ def main():
     loss = None
     nan_steps = 0
     for _ in range(args.steps):
-        latents, loss = one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+        latents, loss = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
         if not args.no_nan_check:            # the loop body's NaN test (pipeline_musicldm.py:741-742): one host sync per step
             nan_steps += int(bool(torch.isnan(loss).any()))
         k += 1
@@ -193,16 +275,49 @@ def main():
     dev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
     if world > 1:
-        import torch.distributed as dist
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     finite = bool(torch.isfinite(loss).all()) and bool(torch.isfinite(latents).all())
+
+    # ---- after the loop: final decode of this rank's clips and the path's only collective, one all_gather of (B, L) waveforms
+    from diffmusic_amd import parallel
+    torch.cuda.synchronize()
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record()
+    mel = pipe.vae.decode(latents / pipe.vae.config.scaling_factor).sample
+    audio = pipe.vocoder(mel.squeeze(1))[:, :L].float().contiguous()
+    e1.record()
+    barrier()
+    tg = time.perf_counter()
+    gathered = parallel.gather_waveforms(audio, B * world)
+    torch.cuda.synchronize()
+    gather_ms = 1e3 * (time.perf_counter() - tg)
+    assert gathered.shape == (B * world, L)
+    finite = finite and bool(torch.isfinite(gathered).all())
+    final_decode_ms = e0.elapsed_time(e1)
+
+    # ---- per-stage device times (HIP events around each stage, 2 extra steps) + the STFT / mel sub-path's achieved HBM rate
+    stages = mel_path = None
+    if not args.no_stage_times:
+        from diffmusic_amd import profiling
+        profiling.enable(events=True)
+        for _ in range(2):
+            one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
+        stages = {kk: round(v, 3) for kk, v in profiling.stage_ms().items()}
+        profiling.enable(events=False)
+        mel_ms = stages.get("operator_mel_loss_fwd_bwd")
+        if mel_ms:
+            by = MEL_PATH_BYTES_PER_CLIP_STEP * B
+            mel_path = {"algorithmic_bytes": int(by), "stage_ms": mel_ms, "achieved_GBps": round(by / (mel_ms * 1e-3) / 1e9, 2),
+                        "peak_GBps": PEAK_HBM_GBPS, "frac": round(by / (mel_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5),
+                        "note": "operator + transform (STFT, mel, dB) + L2 + hand-written backward + per-clip gradient rescale, HIP events around the "
+                                "stage; algorithmic bytes = fused-ideal 2.4 MB per clip-step (SURVEY.md section 8d); per-kernel times in profiles/"}
 
     # ---- roofline leg: one extra step with HIP events around every implicit-GEMM launch
     import ctypes as C
     from diffmusic_amd import _lib as Lb
     Lb.lib().dmx_prof_begin()
-    one_step(pipe, latents, ts[k % N_STEPS], pe2, measurement, L)
+    one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
     ms, fl = C.c_double(), C.c_double()
     n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
     # headline config: the analytic count of BASELINE.md; other workloads: the FLOPs the launches actually issued
@@ -224,35 +339,63 @@ def main():
                 "all_gemm_kernels": {"launches_per_step": n_launch, "kernel_ms_per_step": round(ms.value, 3),
                                      "algorithmic_tflop_per_step": round(algo_tflop_step, 2), "issued_tflop_per_step": round(fl.value / 1e12, 2),
                                      "achieved": round(all_rate, 1), "frac": round(all_rate / PEAK_TFLOPS_16BIT, 4)},
+                "whole_step": {"achieved": round(algo_tflop_step / (wall / args.steps), 1), "frac": round(algo_tflop_step / (wall / args.steps) / PEAK_TFLOPS_16BIT, 4)},
                 "step_share": round(ms.value / (1e3 * wall / args.steps), 3)}
 
+    rc = 0
     if rank == 0:
         steps_per_s = args.steps / wall * world                 # one step advances B clips on each of `world` GPUs
-        res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4),
+        wl_text = {"dps_inpainting": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU (BASELINE.json configs[1])"}.get(
+            wl, f"{wl}: {WORKLOADS[wl][0]} + {WORKLOADS[wl][1]} {WORKLOADS[wl][4]}, 10 s @16 kHz, {n_sched}-step schedule, {WORKLOADS[wl][6]}")
+        res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4) if finite else None,
                "unit": f"steps/s (each step advances a batch of {B} clips per GPU)", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": {"dps_inpainting": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU "
-                                      "(BASELINE.json configs[1])"}.get(wl, f"{wl}: {WORKLOADS[wl][0]} + {WORKLOADS[wl][1]} {WORKLOADS[wl][4]}, 10 s @16 kHz, "
-                                                                        f"200-step schedule, {WORKLOADS[wl][6]}"),
-                          "global_batch": B * world, "clips_per_gpu": B,
-                          "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world}",
-                          "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_check_per_step": not args.no_nan_check,
-                          "final_loss_clip0": float(loss.reshape(-1)[0])},
-               "roofline": roofline}
+               "config": {"workload": wl_text, "global_batch": B * world, "clips_per_gpu": B,
+                          "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world} ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL'} world size {world}, no per-step collective)",
+                          "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_steps": nan_steps,
+                          "nan_check_per_step": not args.no_nan_check, "final_loss_clip0": float(loss.reshape(-1)[0]),
+                          "cached_reference_transform": bool(getattr(op, "cache_reference", False)),
+                          "unet_hip_graph": bool(getattr(pipe.unet, "use_graph", False)),
+                          "launched_by": "bench.py spawn" if os.environ.get("DMX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
+               "after_loop": {"final_decode_ms": round(final_decode_ms, 3), "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
+                              "gather_bytes_per_rank": int(audio.numel() * 4), "gather_world_size": world,
+                              "collective": "all_gather of (clips_per_gpu, 160000) fp32 waveforms, once per call" if world > 1 else "none (single rank)"},
+               "stage_ms": stages, "mel_path": mel_path, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting":
             threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share, not the host's core count
             sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
             print(f"[bench] timing the CPU oracle on {threads} threads (1 clip x 4 steps) ...", file=sys.stderr, flush=True)
-            sec = cpu_baseline(sd, threads)
-            print(f"[bench] CPU oracle: {sec:.2f} s per clip-step", file=sys.stderr, flush=True)
-            res["cpu_baseline"] = {"value": round(1.0 / (sec * B), 6), "unit": "steps/s (batch-8 equivalent, extrapolated from 1 clip)",
-                                   "cores": threads, "kind": "port",
-                                   "sample": f"1 clip x 3 DPS steps after 1 warm-up (U-Net 2x fwd + guided step each), fp32 eager torch + autograd, {sec:.2f} s/step"}
+            sec1 = cpu_baseline(sd, threads, 1)
+            print(f"[bench] CPU oracle: {sec1:.2f} s per clip-step", file=sys.stderr, flush=True)
+            cb = args.cpu_batch
+            if cb == 0:
+                try:
+                    import psutil
+                    avail = psutil.virtual_memory().available / 2 ** 30
+                except Exception:
+                    avail = 0.0
+                cb = next((b for b in (8, 4, 2) if 12.0 * b + 8.0 < 0.6 * avail), 1)      # ~12 GiB of autograd state per clip
+            secb = None
+            if cb > 1:
+                print(f"[bench] timing the CPU oracle at batch {cb} (1 step) ...", file=sys.stderr, flush=True)
+                secb = cpu_baseline(sd, threads, cb)
+                print(f"[bench] CPU oracle: {secb:.2f} s per batch-{cb} step", file=sys.stderr, flush=True)
+            v8 = 1.0 / (secb * (8.0 / cb)) if secb else 1.0 / (sec1 * B)
+            res["cpu_baseline"] = {"value": round(v8, 6), "unit": "steps/s (batch-8 step)" if cb == 8 else "steps/s (batch-8 equivalent, extrapolated)",
+                                   "cores": threads, "kind": "port", "cpu_model": cpu_model_string(), "torch": torch.__version__,
+                                   "batch1_seconds_per_step": round(sec1, 3), f"batch{cb}_seconds_per_step": round(secb, 3) if secb else None,
+                                   "gpu_over_cpu": round(steps_per_s / v8, 1),
+                                   "sample": f"oracle/ (fp32 eager torch + autograd, U-Net 2x fwd + guided step): 1 clip x 3 DPS steps after 1 warm-up "
+                                             f"({sec1:.2f} s/step)" + (f"; {cb} clips x 1 DPS step ({secb:.2f} s/step)" if secb else "")}
         print(json.dumps(res), flush=True)
+        if not finite:
+            print(f"[bench] non-finite loss / latents / waveforms (nan_steps={nan_steps}): value set to null", file=sys.stderr)
+            rc = 4
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

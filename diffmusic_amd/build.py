@@ -11,6 +11,16 @@ LIB = os.path.join(HERE, "lib", "libdiffmusic_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("DMX_EXTRA_FLAGS", "").split()
 
 
+STAMP = os.path.join(OBJ, "flags.stamp")
+
+
+def _flags_key(hipcc):
+    """Everything besides the sources that decides what the objects contain: compiler path + the full flag list (DMX_EXTRA_FLAGS
+    included).  A library built with other flags (e.g. an ablation build of a dev script) is rebuilt, never reused."""
+    import hashlib
+    return hashlib.sha256(("\0".join([hipcc] + FLAGS)).encode()).hexdigest()
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -25,6 +35,14 @@ def build_library(force=False, verbose=False):
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "diffmusic_hip.h"))
+    key = _flags_key(hipcc)
+    try:
+        with open(STAMP) as fh:
+            same_flags = fh.read().strip() == key
+    except OSError:
+        same_flags = False
+    if not same_flags:
+        force = True                      # objects of unknown / different flags: rebuild everything
     objs, jobs = [], []
     for s in srcs:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
@@ -50,6 +68,8 @@ def build_library(force=False, verbose=False):
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    with open(STAMP, "w") as fh:
+        fh.write(key + "\n")
     return LIB
 
 

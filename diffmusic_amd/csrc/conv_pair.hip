@@ -137,9 +137,7 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
     for (int it = 0; it < K::SLAB_IT; ++it) {
       const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = tfirst + row;
       sv[it] = make_uint4(0, 0, 0, 0);
-#ifndef DMX_PAIR_NOLOAD
       if (row < nrows && t >= 0 && t < T) sv[it] = *reinterpret_cast<const uint4*>(src + ((long long)b * T + t) * C + piece * 8);
-#endif
     }
     const bool masked = !single && (P.a.flags & EPI_MASK);
     uint4 mv[K::BITS_IT];
@@ -295,11 +293,7 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
 #pragma unroll
       for (int it = 0; it < K::BITS_IT; ++it) {
         const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
-#ifdef DMX_PAIR_NOMID
-        if (row == -12345)
-#else
         if (row >= P.loB && row < P.loB + P.BMo && t < T)
-#endif
           *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
       }
     }
@@ -314,9 +308,6 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
     static_assert(EPI_WAVE_BYTES * NW <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
     const int mbase = b * T + t0;
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
-#ifdef DMX_PAIR_NOEPI
-    if (P.b.alpha == 12345.f)
-#endif
     gemm_epilogue_lds_impl<4, FN>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
                                   !single && P.r_from_slab != 0);
   }

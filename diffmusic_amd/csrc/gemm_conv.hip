@@ -1,13 +1,12 @@
-// Implicit-GEMM convolution / batched NT-GEMM on gfx950 MFMA (bf16 in, fp32 accumulate).
+// Implicit-GEMM convolution / batched NT-GEMM on gfx950 MFMA (fp16 in -- bf16 with -DDMX_BF16 --, fp32 accumulate).
 //
 // One kernel family serves every dense contraction on the hot path ("the
 // kernel family is closed under dgrad"): conv1d (dilated), ConvTranspose1d (one launch per output
 // phase), strided conv1d (ConvTranspose dgrad), conv2d 3x3/1x1/stride-2, linear layers and the
-// attention products.  Activations are channels-last bf16 so the K axis (tap, cin) is contiguous
-// per tap; the A tile is gathered with zero fill at the borders, staged through registers into an
-// XOR-swizzled LDS image and consumed by v_mfma_f32_16x16x32_bf16 with the weight as the MFMA
-// A-operand, so each lane ends up with 4 consecutive output channels of one output pixel (8-byte
-// channels-last stores).  Everything pointwise around a contraction (bias, time-embedding row bias,
+// attention products.  Activations are channels-last 16-bit so the K axis (tap, cin) is contiguous
+// per tap; the A tile is gathered with zero fill at the borders into an XOR-swizzled LDS image (LDS-DMA
+// in gemm_glds_kernel, register-staged in gemm_kernel) and consumed by v_mfma_f32_16x16x32_f16 with the
+// weight as the MFMA A-operand, so each lane ends up with 4 consecutive output channels of one output pixel.  Everything pointwise around a contraction (bias, time-embedding row bias,
 // residual, resblock averaging, leaky-relu of the stored activation, leaky-relu' mask for dgrad,
 // tanh) is fused into the epilogue.
 #include "dmx_common.h"
@@ -18,11 +17,7 @@
 
 namespace {
 
-#ifndef DMX_NO_SWP
-#define DMX_SWP 1   // hand-scheduled fragment pipeline in the LDS-DMA kernels (default on)
-#endif
-
-constexpr int BK = 64;  // bf16 elements per K-step (128 B per tile row)
+constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
 
 
 template <int BM, int BN, int WM, int WN>
@@ -172,11 +167,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 // (l&7)^(l>>3) of row l>>3).  Conv zero padding, M/N/K tails: the lane's buffer offset is sent out of
 // range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
 constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
-#ifdef DMX_NOLOAD
-constexpr unsigned NUMREC = 0u;          // timing-only build: every LDS-DMA is range-checked away (zeros)
-#else
-constexpr unsigned NUMREC = OOB;
-#endif
 
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
@@ -199,8 +189,8 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const act_t* Wb = p.W + zo * p.sWo + zi * p.sWi;
   const int nsplit = p.ksplit > 1 ? p.ksplit : 1, sp = blockIdx.z;     // split-K: this workgroup owns K steps [ks0, ks1)
   const long long coff = zo * p.sCo + zi * p.sCi + (nsplit > 1 ? (long long)sp * p.M * p.N : 0ll);
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, NUMREC, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, NUMREC, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, OOB, 0x00020000);
 
   if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
 
@@ -284,12 +274,9 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
   for (int ks = 0; ks < nk; ++ks) {
-#if !defined(DMX_ISSUE_MID) && !defined(DMX_NOISSUE)
     issue(ks + NSTAGE - 1, nxt);
-#endif
     const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
     const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
-#ifdef DMX_SWP
     {
       // Hand-scheduled fragment pipeline.  hipcc sinks every ds_read next to its consumer (read 2, wait, 4-8 MFMAs: the LDS
       // latency is exposed 16x per K-step and the matrix pipe idles ~50 %).  Here the reads are inline asm issued two steps
@@ -331,63 +318,14 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
         __builtin_amdgcn_sched_barrier(0);
       });
 #undef DMX_DSR
-#ifdef DMX_ISSUE_MID
-      issue(ks + NSTAGE - 1, nxt);
-#endif
     }
-#else
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int sw = ((kk * 4 + lq) ^ (lr & 7)) << 4;
-      frag8_t wf[FN];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) wf[j] = *reinterpret_cast<const frag8_t*>(sb + j * 16 * 128 + sw);
-#ifdef DMX_PREFETCH_A
-      frag8_t af[FM];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
-#endif
-#ifdef DMX_SETPRIO
-      __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-#ifdef DMX_PREFETCH_A
-        const frag8_t a = af[i];
-#else
-        const frag8_t a = *reinterpret_cast<const frag8_t*>(sa + i * 16 * 128 + sw);
-#endif
-#pragma unroll
-#ifdef DMX_NOMFMA
-        asm volatile("" ::"v"(a));
-        if (i == 0) {
-#pragma unroll
-          for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(wf[j]));
-        }
-#else
-        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(wf[j], a, acc[i][j]);
-#endif
-      }
-#ifdef DMX_SETPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
-#if defined(DMX_ISSUE_MID) && !defined(DMX_NOISSUE)
-      if (kk == 0) issue(ks + NSTAGE - 1, nxt);
-#endif
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
-#ifndef DMX_NOBARRIER
     __builtin_amdgcn_s_barrier();
-#endif
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill tail ...
   __builtin_amdgcn_s_barrier();                          // ... of every wave before the stage buffers are reused by the epilogue
-#ifdef DMX_NOEPI
-  if (p.alpha == 12345.f)
-#endif
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
@@ -413,23 +351,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   glds_tile<BM, BN, WM, WN, NSTAGE>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
 }
 
-// Two tile heights in one launch, alternating along M.  With uniform tiles every workgroup reaches its epilogue at the same
-// moment: HBM sits idle during the K loops and is the bottleneck during the simultaneous epilogue bursts (the store / residual
-// traffic of a 160 032 x 256 layer runs at ~3 TB/s for ~30 us per round while the matrix cores wait).  Tiles of BMA and BMB rows
-// take different times, so after the first tiles the workgroups drift apart and the epilogue traffic of some overlaps the K
-// loops of the others.
-template <int BMA, int BMB, int BN, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_glds_mixed_kernel(const GemmDesc p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tiles_n = (p.N + BN - 1) / BN;
-  const int bid = xcd_remap(blockIdx.x);
-  const int tmi = bid / tiles_n, tn = bid - tmi * tiles_n;
-  const int m0 = (tmi >> 1) * (BMA + BMB) + ((tmi & 1) ? BMA : 0);
-  if (m0 >= p.M) return;
-  if (tmi & 1) glds_tile<BMB, BN, WM, WN, NSTAGE>(p, smem, m0, tn);
-  else glds_tile<BMA, BN, WM, WN, NSTAGE>(p, smem, m0, tn);
-}
-
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_glds(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
@@ -443,23 +364,6 @@ int launch_glds(const GemmDesc& d, hipStream_t stream) {
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
   hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
-  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
-}
-
-template <int BMA, int BMB, int BN, int WM, int WN, int NSTAGE>
-int launch_glds_mixed(const GemmDesc& d, hipStream_t stream) {
-  constexpr int NT = WM * WN * 64;
-  constexpr int BMX = BMA > BMB ? BMA : BMB;
-  constexpr int SMEM = NSTAGE * (BMX + BN) * 128 + DMX_MAX_TAPS * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_mixed_kernel<BMA, BMB, BN, WM, WN, NSTAGE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    attr_set = true;
-  }
-  const long long tiles = 2ll * cdiv(d.M, BMA + BMB) * cdiv(d.N, BN);
-  dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
-  hipLaunchKernelGGL((gemm_glds_mixed_kernel<BMA, BMB, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
@@ -494,9 +398,7 @@ std::vector<ProfRec> g_prof_recs;
 // tile configurations: 1 = LDS-DMA 256x256, 2 = LDS-DMA 256x128, 3 = 128x128, 4 = 128x64, 5 = 128x32, 6 = 64x64
 struct TileEntry { int M, N, K, Z, cfg; };
 static const TileEntry g_tile_table[] = {
-#ifndef DMX_NO_TILE_TABLE
 #include "tile_table.inc"
-#endif
     {0, 0, 0, 0, 0}};
 
 bool glds_ok(const GemmDesc& d) {
@@ -516,12 +418,6 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 12: return launch_glds<64, 64, 2, 2, 4>(d, stream);
     case 13: return launch_glds<128, 64, 2, 2, 3>(d, stream);
     case 14: return launch_glds<64, 128, 2, 2, 3>(d, stream);
-#ifdef DMX_MIXED_TILES      // experiment (measured slower): two tile heights in one launch
-    case 15: return launch_glds_mixed<320, 192, 256, 2, 4, 2>(d, stream);
-    case 16: return launch_glds_mixed<320, 192, 128, 4, 2, 2>(d, stream);
-    case 17: return launch_glds_mixed<320, 256, 256, 2, 4, 2>(d, stream);
-    case 18: return launch_glds_mixed<256, 192, 256, 2, 4, 2>(d, stream);
-#endif
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -531,7 +427,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 14 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
     static int ovN[8], ovC[8], nov = -1;
     if (nov < 0) {
@@ -568,9 +464,6 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     double bc = 1e30;
     for (const Cand& c : cands) {
       if (c.bn == 256 && d.N % 256) continue;
-#ifdef DMX_NO_EXTRA_TILES
-      if (c.cfg >= 7) continue;
-#endif
       const double v = cost(c.bm, c.bn, c.slots, c.eff);
       if (v < bc) { bc = v; best = c.cfg; }
     }
@@ -612,7 +505,7 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
     if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
-    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10) || (r.cfg >= 15 && r.cfg <= 18);   // gemm_glds_kernel, 8-wave tiles (256/320/192 rows)
+    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10);   // gemm_glds_kernel, 8-wave tiles (256/320/192 rows)
     if (dma) { g_dma_ms += t; g_dma_fl += r.flops; g_dma_by += r.bytes; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);

@@ -147,17 +147,10 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       const int m = m0 + hh * CH + it * RPI + rr;
       const bool ok = m < mend && col_ok;
       const long long off = ok ? (long long)m * ldfirst + ncol : 0ll;
-#ifndef DMX_EPI_NOLOAD
       pre[it] = *reinterpret_cast<const uint4*>(Gfirst + coff + off);
-#else
-      pre[it] = make_uint4(0, 0, 0, 0);
-#endif
       if (!ok) pre[it] = make_uint4(0, 0, 0, 0);
     }
   };
-#ifdef DMX_EPI_PREFETCH
-  if (prefetch) issue_pre(0);
-#endif
 #pragma unroll
   for (int h = 0; h < FM / IB; ++h) {
     // ---- output row of each tile row this lane touches in the row-major phases
@@ -187,11 +180,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`.  All loads of a chunk are issued back to
     // back from always-valid addresses (out-of-range rows read element 0 and are zeroed): one exposed latency per tensor.
     auto stage_in = [&](int which, const act_t* G, int ld, auto&& f) {
-#ifdef DMX_EPI_PREFETCH
-      const bool from_pre = prefetch && which == first;
-#else
       const bool from_pre = false;
-#endif
       if (from_pre) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = pre[it];
@@ -201,11 +190,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         for (int it = 0; it < NIT; ++it) {
           const bool ok = orows[it] >= 0 && col_ok;
           const long long off = ok ? (long long)orows[it] * ld + ncol : 0ll;
-#ifndef DMX_EPI_NOLOAD
           v[it] = *reinterpret_cast<const uint4*>(G + coff + off);
-#else
-          v[it] = make_uint4(0, 0, 0, 0);
-#endif
           if (!ok) v[it] = make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
@@ -242,11 +227,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       //  keep v[] in scratch: every output byte was written twice.)
 #pragma unroll
       for (int it = 0; it < HN; ++it) {
-#ifndef DMX_EPI_NOSTORE
         if (orows[g0 + it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
-#else
-        if (orows[g0 + it] == -12345 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
-#endif
       }
       }
     };
@@ -270,11 +251,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           if (n >= p.N) continue;
           f32x4& a = acc[h * IB + ii][j];
           if (flags & EPI_BIAS) {
-#ifdef DMX_EPI_BIAS_INLOOP
-            const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-#else
             const float4 bb = bcol[j];
-#endif
             a[0] += bb.x; a[1] += bb.y; a[2] += bb.z; a[3] += bb.w;
           }
           if (flags & EPI_ROWBIAS) {
@@ -317,9 +294,6 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
     }
-#ifdef DMX_EPI_PREFETCH
-    if (prefetch && h + 1 < FM / IB) issue_pre(h + 1);
-#endif
     if (!(flags & EPI_NO_C)) {
       stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
       DMX_LDS_SYNC();

@@ -456,5 +456,9 @@ size_t dmx_unet_ws_impl(Model* m, int B, int h, int w, int n0, int n1) {
 }
 int dmx_unet_fwd_impl(Model* m, const float* x, const float* t, const float* cls, float* eps, int B, int h, int w, void* ws, size_t wsb,
                       hipStream_t st, const float* c0, int n0, const float* c1, int n1, const float* bias1) {
-  return static_cast<UNet*>(m)->forward(x, t, cls, eps, B, h, w, ws, wsb, st, c0, n0, c1, n1, bias1);
+  const int rc = static_cast<UNet*>(m)->forward(x, t, cls, eps, B, h, w, ws, wsb, st, c0, n0, c1, n1, bias1);
+  // the split-K scratch is installed for this executor's launches only: later VAE / HiFi-GAN launches (possibly on other
+  // streams) must not pick it up, or their numerics would depend on whether a U-Net ran earlier in the process
+  dmx_gemm_set_splitk_workspace(nullptr, 0);
+  return rc;
 }

@@ -133,12 +133,21 @@ class BaseOperator:
 
     # ---- guided-step extension -------------------------------------------------------------
     _ref_cache = None
+    cache_reference = True     # False: recompute transform(measurement) every step, as the reference does (operator.py:205-206 call site)
 
-    def _ref(self, measurement, fn):
-        key = (measurement.data_ptr(), tuple(measurement.shape), measurement._version)
-        if self._ref_cache is None or self._ref_cache[0] != key:
-            self._ref_cache = (key, fn(measurement))      # `transform(y)` is constant over the trajectory
-        return self._ref_cache[1]
+    def reset_cache(self):
+        """Forget the cached `transform(measurement)`; called at the start of every trajectory (set_timesteps / __call__)."""
+        self._ref_cache = None
+
+    def _ref(self, measurement, space, fn):
+        """`transform(y)` is constant over a trajectory: computed once per measurement TENSOR and supervised space.  The
+        cache entry holds the tensor itself (identity comparison + version counter), which also keeps its storage alive,
+        so a later measurement can never be handed the same address by the caching allocator and hit a stale entry."""
+        c = self._ref_cache
+        if not self.cache_reference or c is None or c[0] is not measurement or c[1] != measurement._version or c[2] != space:
+            c = (measurement, measurement._version, space, fn(_as_f32_cuda(measurement)))
+            self._ref_cache = c
+        return c[3]
 
     def guidance(self, wav, length, measurement, supervised_space):
         raise NotImplementedError
@@ -168,11 +177,11 @@ class _MelOperator(BaseOperator):
 
     def guidance(self, wav, length, measurement, supervised_space):
         y = self._a_fwd(wav, length)                                         # (B, L') contiguous fp32
-        measurement = _as_f32_cuda(measurement)
         if supervised_space == "wav_form":
-            loss, dy = l2_loss(measurement.reshape(measurement.shape[0], -1), y)
+            m32 = self._ref(measurement, "wav_form", lambda m: m.reshape(m.shape[0], -1).contiguous())
+            loss, dy = l2_loss(m32, y)
         elif supervised_space == "mel_spectrogram":
-            ref = self._ref(measurement, lambda m: self._mel(m.reshape(m.shape[0], -1)).clone())
+            ref = self._ref(measurement, "mel_spectrogram", lambda m: self._mel(m.reshape(m.shape[0], -1)).clone())
             pred = self._mel(y)
             loss, dmel = l2_loss(ref, pred)
             dy = self.frontend.transform_bwd(dmel)
@@ -275,17 +284,17 @@ class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
         return self.noiser(mag) if self.noiser is not None else mag
 
     def guidance(self, wav, length, measurement, supervised_space):
-        measurement = _as_f32_cuda(measurement)
         if supervised_space == "wav_form":          # scheduling_dps.py:199-201: || y - |STFT(wav)| ||_2 on the raw magnitudes
             mag = self.frontend.stft_mag(wav, length)
             B = mag.shape[0]
-            loss, dmag = l2_loss(measurement.reshape(B, -1), mag.reshape(B, -1))
+            m32 = self._ref(measurement, "wav_form", lambda m: m.reshape(m.shape[0], -1).contiguous())
+            loss, dmag = l2_loss(m32, mag.reshape(B, -1))
             dwav = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)
             self.frontend.stft_mag_bwd(dmag.reshape(mag.shape), length, dwav)
             return loss, dwav
         if supervised_space != "mel_spectrogram":
             raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
-        ref = self._ref(measurement, lambda m: self.frontend.melscale(m, -80.0, 80.0))
+        ref = self._ref(measurement, "mel_spectrogram", lambda m: self.frontend.melscale(m, -80.0, 80.0))
         pred = self.frontend.transform_fwd(wav, length, False, False, -80.0, 80.0)   # |STFT| -> MelScale -> clamp
         loss, dmel = l2_loss(ref, pred)
         dwav = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)

@@ -18,6 +18,9 @@ def gather_waveforms(local, n_clips, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = (n_clips + world - 1) // world
     L = local.shape[1]
+    dev = local.device
+    if local.is_cuda and dist.get_backend(group) == "gloo":     # gloo has no device all_gather: stage through the host
+        local = local.cpu()
     pad = torch.zeros(per, L, dtype=local.dtype, device=local.device)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
@@ -26,4 +29,4 @@ def gather_waveforms(local, n_clips, group=None):
     for r in range(world):
         idx = shard_indices(n_clips, r, world)
         out[idx] = parts[r][: len(idx)]
-    return out
+    return out.to(dev)

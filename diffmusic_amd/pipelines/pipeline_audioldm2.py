@@ -30,6 +30,17 @@ class AudioLDM2Pipeline(MusicLDMPipeline):
             pe, ge, am = torch.cat([npe, pe]), torch.cat([nge, ge]), torch.cat([nam, am])
         return dict(class_labels=None, encoder_hidden_states=ge, encoder_hidden_states_1=pe, encoder_attention_mask_1=am)
 
+    def _needs_negative_embeds(self):
+        return False            # the unconditional branch is built per context in _prepare_cond (:640-668)
+
+    def _optim_prompt_step(self, noise_pred, t, latents, cond, measurement, length, lr, supervised_space, extra):
+        """plpeline_audioldm2.py:1161-1176: both contexts go through scheduler.optim_prompt and come back (unchanged)."""
+        out = self.scheduler.optim_prompt(noise_pred, t, latents, measurement=measurement, original_waveform_length=length,
+                                          vae=self.vae, vocoder=self.vocoder, encoder_hidden_states=cond["encoder_hidden_states"],
+                                          encoder_hidden_states_1=cond["encoder_hidden_states_1"], optim_prompt_learning_rate=lr,
+                                          supervised_space=supervised_space, **extra)
+        return dict(cond, encoder_hidden_states=out.encoder_hidden_states, encoder_hidden_states_1=out.encoder_hidden_states_1)
+
     def __call__(self, prompt=None, transcription=None, audio_length_in_s=None, num_inference_steps=200, guidance_scale=3.5,
                  negative_prompt=None, num_waveforms_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, generated_prompt_embeds=None, negative_generated_prompt_embeds=None,

@@ -9,6 +9,7 @@ Extension: all B clips are returned (the reference returns clip 0 only, :781).""
 import contextlib
 import inspect
 import os
+import warnings
 from types import SimpleNamespace
 
 import numpy as np
@@ -17,6 +18,8 @@ import torch
 from .. import _lib as L
 from ..engine import HifiGanEngine, UNetEngine, VaeDecoderEngine
 from ..torch_utils import randn_tensor
+from ..profiling import stage
+from .. import parallel
 
 import ctypes as C
 
@@ -111,7 +114,10 @@ class MusicLDMPipeline:
         """MusicLDM: CLAP text embedding (B, 512) as class_labels; [uncond | text] on the CFG batch (:243-248)."""
         pe = prompt_embeds.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
         if do_cfg:
-            ne = negative_prompt_embeds if negative_prompt_embeds is not None else prompt_embeds   # prompt="" -> cond == uncond
+            # the reference encodes negative_prompt (default "") with CLAP as the unconditional branch (:208-238); __call__ does
+            # that when a text front end is attached.  Without one the caller states cond == uncond (prompt="" everywhere in
+            # run.py:122) by leaving negative_prompt_embeds None -- __call__ warns about it once.
+            ne = negative_prompt_embeds if negative_prompt_embeds is not None else prompt_embeds
             ne = ne.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
             pe = torch.cat([ne, pe], dim=0)
         return dict(class_labels=pe)
@@ -124,18 +130,19 @@ class MusicLDMPipeline:
         if not isinstance(cond, dict):
             cond = dict(class_labels=cond)
         x = latents.to(torch.float32).contiguous()
-        B = x.shape[0]
-        if not do_cfg:
-            return self.unet.forward(x, torch.full((B,), float(t_host)), **cond)
-        if self.dedupe_cfg and self._cond_is_symmetric(cond, B):
-            half = {k: (v[:B] if v is not None else None) for k, v in cond.items()}
-            return self.unet.forward(x, torch.full((B,), float(t_host)), **half)                   # uncond + s*(text-uncond) == text
-        x2 = torch.cat([x, x], dim=0)
-        eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host)), **cond)
-        out = torch.empty_like(x)
-        L.check(L.lib().dmx_sched_cfg_combine(C.c_void_p(eps2.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(), float(guidance_scale),
-                                              _stream()), "cfg_combine")
-        return out
+        B, dev = x.shape[0], x.device
+        with stage("unet_cfg"):
+            if not do_cfg:
+                return self.unet.forward(x, torch.full((B,), float(t_host), device=dev), **cond)
+            if self.dedupe_cfg and self._cond_is_symmetric(cond, B):
+                half = {k: (v[:B] if v is not None else None) for k, v in cond.items()}
+                return self.unet.forward(x, torch.full((B,), float(t_host), device=dev), **half)   # uncond + s*(text-uncond) == text
+            x2 = torch.cat([x, x], dim=0)
+            eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host), device=dev), **cond)
+            out = torch.empty_like(x)
+            L.check(L.lib().dmx_sched_cfg_combine(C.c_void_p(eps2.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),
+                                                  float(guidance_scale), _stream()), "cfg_combine")
+            return out
 
     # ---- the call ---------------------------------------------------------------------------
     @torch.no_grad()
@@ -144,17 +151,26 @@ class MusicLDMPipeline:
                  negative_prompt_embeds=None, return_dict=True, callback=None, callback_steps=1, cross_attention_kwargs=None,
                  output_type="np", measurement=None, optim_prompt=False, ip_guidance_rate=0.0005,
                  optim_prompt_learning_rate=0.0001, optim_outer_loop=1, show_progress=True, prompt_type=None,
-                 supervised_space="mel_spectrogram"):
+                 supervised_space="mel_spectrogram", shard=False, group=None):
+        """Reference signature (pipeline_musicldm.py:493-519) plus `shard` / `group` (extension): with
+        torch.distributed initialised, `shard=True` (or a process `group`) makes every rank run clips k = rank, rank + G, ... of
+        the batch and all-gathers the finished waveforms once at the end (RCCL over xGMI); every rank returns all B clips."""
+        front = getattr(self, "text_frontend", None)
+        do_cfg = guidance_scale > 1.0
         if prompt_embeds is None:
-            front = getattr(self, "text_frontend", None)
             if front is None or prompt is None:
                 raise NotImplementedError("no text front end attached: pass prompt_embeds (B, 512), or set pipe.text_frontend = "
                                           "ClapTextFrontEnd(...) (diffmusic_amd/pipelines/prompt.py) to use `prompt=`")
-            prompt_embeds, ne = front.encode(prompt, negative_prompt, guidance_scale > 1.0)     # pipeline_musicldm.py:119-250
+            prompt_embeds, ne = front.encode(prompt, negative_prompt, do_cfg)                  # pipeline_musicldm.py:119-250
             if negative_prompt_embeds is None:
                 negative_prompt_embeds = ne
-        if optim_prompt:
-            raise NotImplementedError("optim_prompt is a no-op in the reference and disabled in every config")
+        elif do_cfg and negative_prompt_embeds is None and self._needs_negative_embeds():
+            if front is not None:                                   # the reference's unconditional branch: CLAP("") (:208-238)
+                negative_prompt_embeds = front.encode([negative_prompt or ""] * prompt_embeds.shape[0], None, False)[0]
+            elif not self.assume_uncond_equals_cond:
+                warnings.warn("prompt_embeds given without negative_prompt_embeds and no text front end attached: the unconditional "
+                              "CFG branch reuses prompt_embeds, which equals the reference only for prompt=\"\" (its default, "
+                              "run.py:122); pass negative_prompt_embeds or set pipe.assume_uncond_equals_cond = True", stacklevel=2)
         vcfg = self.vocoder.config
         vocoder_upsample_factor = np.prod(vcfg.upsample_rates) / vcfg.sampling_rate               # :602
         if audio_length_in_s is None:
@@ -165,61 +181,117 @@ class MusicLDMPipeline:
             height = int(np.ceil(height / self.vae_scale_factor)) * self.vae_scale_factor
         device = self.device
         batch_size = prompt_embeds.shape[0]
-        do_cfg = guidance_scale > 1.0
         pe = self._prepare_cond(prompt_embeds, negative_prompt_embeds, num_waveforms_per_prompt, do_cfg, device,
                                 **getattr(self, "_extra_cond", {}))
         self.scheduler.set_timesteps(num_inference_steps, device=device)
         timesteps = list(self.scheduler._timesteps_host)
         nlat = self.unet.cfg["in_channels"]
-        B = batch_size * num_waveforms_per_prompt
-        latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, latents)
-        extra = self.prepare_extra_step_kwargs(generator, eta)
+        B_all = B = batch_size * num_waveforms_per_prompt
         if measurement is not None:
-            measurement = measurement.to(device)
-        init_latents = latents
+            measurement = measurement.to(device=device, dtype=torch.float32)      # once per call (transform(y) is cached per tensor)
+        # ---- clip sharding (no per-step collective; clips are independent because norms and RNG are per clip)
+        sel = None
+        if shard or group is not None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("shard=True needs an initialised torch.distributed process group")
+            if isinstance(generator, torch.Generator):
+                raise ValueError("clip sharding needs one generator per clip (a list of length B) so that the noise does not "
+                                 "depend on the number of ranks")
+            sel = parallel.shard_indices(B_all, dist.get_rank(group), dist.get_world_size(group))
+            rows = sel + [B_all + k for k in sel] if do_cfg else sel
+            pe = {k: (v[rows] if v is not None else None) for k, v in pe.items()}
+            if isinstance(generator, (list, tuple)):
+                if len(generator) != B_all:
+                    raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                                     f"batch size of {B_all}.")
+                generator = [generator[k] for k in sel]
+            if latents is not None:
+                latents = latents[sel]
+            if measurement is not None and measurement.shape[0] == B_all and B_all > 1:
+                measurement = measurement[sel].contiguous()
+            B = len(sel)
+        extra = self.prepare_extra_step_kwargs(generator, eta)
         self.last_losses = []
-        for _ in range(optim_outer_loop):
-            retry = 10
-            latents = init_latents
-            while True:
-                is_done = True
-                pending = []
-                bar = None
-                if show_progress:
-                    from tqdm import tqdm
-                    bar = tqdm(total=num_inference_steps)
-                with bar if bar is not None else contextlib.nullcontext():
-                    for i, t in enumerate(timesteps):
-                        noise_pred = self._unet_eps(self.scheduler.scale_model_input(latents, t), t, pe, guidance_scale, do_cfg)
-                        out = self.scheduler.step(noise_pred, t, latents, measurement=measurement,
-                                                  original_waveform_length=original_waveform_length, vae=self.vae,
-                                                  vocoder=self.vocoder, ip_guidance_rate=ip_guidance_rate,
-                                                  ditto_optimizer=None, init_latents=init_latents,
-                                                  supervised_space=supervised_space, **extra)
-                        pending.append(out.loss)
-                        last = i == len(timesteps) - 1
-                        if (len(pending) >= self.nan_check_every or last) and retry >= 0:
-                            bad = any(bool(torch.isnan(l.float()).any()) for l in pending)      # one host sync per check
-                            self.last_losses.extend(pending)
-                            pending = []
-                            if bad:                                                             # NaN-retry (:741-756)
-                                retry -= 1
-                                latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, None)
-                                is_done = False
-                                break
-                        latents = out.prev_sample.detach()
-                        if bar is not None:
-                            bar.update()
-                        if callback is not None and i % callback_steps == 0:
-                            callback(i, t, latents)
-                if is_done:
-                    break
+        self.nan_restarts = 0
+        if B > 0:
+            latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, latents)
+            init_latents = latents
+            init_pe = pe
+            for _ in range(optim_outer_loop):
+                retry = 10
+                latents = init_latents
+                while True:
+                    is_done = True
+                    pending = []
+                    bar = None
+                    if show_progress:
+                        from tqdm import tqdm
+                        bar = tqdm(total=num_inference_steps)
+                    with bar if bar is not None else contextlib.nullcontext():
+                        for i, t in enumerate(timesteps):
+                            noise_pred = self._unet_eps(self.scheduler.scale_model_input(latents, t), t, pe, guidance_scale, do_cfg)
+                            if optim_prompt and t % 30 == 1:                                        # :710-723
+                                pe = self._optim_prompt_step(noise_pred, t, latents, pe, measurement, original_waveform_length,
+                                                             optim_prompt_learning_rate, supervised_space, extra)
+                            out = self.scheduler.step(noise_pred, t, latents, measurement=measurement,
+                                                      original_waveform_length=original_waveform_length, vae=self.vae,
+                                                      vocoder=self.vocoder, ip_guidance_rate=ip_guidance_rate,
+                                                      ditto_optimizer=None, init_latents=init_latents,
+                                                      supervised_space=supervised_space, **extra)
+                            pending.append(out.loss)
+                            last = i == len(timesteps) - 1
+                            if (len(pending) >= self.nan_check_every or last) and retry >= 0:
+                                bad = any(bool(torch.isnan(l.float()).any()) for l in pending)      # one host sync per check
+                                self.last_losses.extend(pending)
+                                pending = []
+                                if bad:                                                             # NaN-retry (:741-756)
+                                    retry -= 1
+                                    self.nan_restarts += 1
+                                    latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, None)
+                                    is_done = False
+                                    pe = init_pe
+                                    break
+                            latents = out.prev_sample.detach()
+                            if bar is not None:
+                                bar.update()
+                            if callback is not None and i % callback_steps == 0:
+                                callback(i, t, latents)
+                    if is_done:
+                        break
+        else:
+            latents = torch.zeros(0, nlat, int(height) // self.vae_scale_factor, int(vcfg.model_in_dim) // self.vae_scale_factor,
+                                  dtype=torch.float32, device=device)
         if output_type == "latent":
+            if sel is not None:
+                shp = latents.shape[1:]
+                latents = parallel.gather_waveforms(latents.reshape(B, int(np.prod(shp))).contiguous(), B_all, group).reshape(B_all, *shp)
             return AudioPipelineOutput(audios=latents)
-        mel = self.vae.decode(latents / self.vae.config.scaling_factor).sample                 # (B,1,H,W) fp32
-        audio = self.mel_spectrogram_to_waveform(mel)[:, :original_waveform_length]
+        if B > 0:
+            with stage("final_decode"):
+                mel = self.vae.decode(latents / self.vae.config.scaling_factor).sample                 # (B,1,H,W) fp32
+                audio = self.vocoder(mel.squeeze(1))[:, :original_waveform_length].float()         # :428-435, on the device
+        else:
+            audio = torch.zeros(0, original_waveform_length, dtype=torch.float32, device=device)
+        if sel is not None:
+            with stage("gather_waveforms"):
+                audio = parallel.gather_waveforms(audio.contiguous(), B_all, group)                    # the only collective
+        audio = audio.cpu()
         if output_type == "np":
             audio = audio.numpy()
         if not return_dict:
             return (audio,)
         return AudioPipelineOutput(audios=audio)
+
+    assume_uncond_equals_cond = False      # True: prompt_embeds without negative_prompt_embeds means prompt == "" (no warning)
+
+    def _needs_negative_embeds(self):
+        return True
+
+    def _optim_prompt_step(self, noise_pred, t, latents, cond, measurement, length, lr, supervised_space, extra):
+        """The reference's prompt-optimisation hook (pipeline_musicldm.py:710-723): calls scheduler.optim_prompt with the
+        conditioning as encoder_hidden_states_1 and takes the returned embeddings (unchanged: see scheduler.optim_prompt)."""
+        out = self.scheduler.optim_prompt(noise_pred, t, latents, measurement=measurement, original_waveform_length=length,
+                                          vae=self.vae, vocoder=self.vocoder, encoder_hidden_states_1=cond.get("class_labels"),
+                                          optim_prompt_learning_rate=lr, supervised_space=supervised_space, **extra)
+        return dict(cond, class_labels=out.encoder_hidden_states_1)

@@ -14,6 +14,7 @@ import torch
 
 from .. import _lib as L
 from ..torch_utils import randn_tensor
+from ..profiling import stage
 from .utils import InverseProblemSchedulerOutput
 
 _MODE = dict(ddim=0, dps=1, mpgd=2, dsg=3, diffmusic=4)
@@ -91,6 +92,8 @@ class GuidedDDIMScheduler:
         else:
             raise ValueError(f"{sp} is not supported")
         self._timesteps_host = [int(t) for t in ts]
+        if self.operator is not None and hasattr(self.operator, "reset_cache"):
+            self.operator.reset_cache()           # a new trajectory: forget the cached transform(measurement)
         self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
 
     def _get_variance(self, timestep, prev_timestep):
@@ -109,19 +112,24 @@ class GuidedDDIMScheduler:
     # ---- HIP guidance sweep: x0 -> vae -> vocoder -> A -> loss ; and back
     def _guidance(self, x0, measurement, vae, vocoder, length, supervised_space, op_kwargs=None):
         zs = 1.0 / vae.config.scaling_factor
-        mel = vae.decode_hip(x0, z_scale=zs, keep_state=True)              # (B, H, W) fp16
-        wav = vocoder.forward(mel)                                         # (B, Lfull) fp32
-        loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space, **(op_kwargs or {}))
-        if not self.per_clip_norm and loss.numel() > 1:
-            # whole-batch norm: L = sqrt(sum_b L_b^2), dL/dwav_b = (L_b / L) * dL_b/dwav_b  (device-side, B scalars)
-            total = torch.linalg.vector_norm(loss)
-            dwav.mul_((loss / total.clamp_min(1e-30))[:, None])
-            loss = total.reshape(1)
-        inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
-        L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
-                "grad_normalize")
-        dmel = vocoder.backward(dwav)
-        g0 = vae.backward(dmel, z_scale=zs)                                # dLoss/dx0 * (1/inv_scale)
+        with stage("vae_fwd"):
+            mel = vae.decode_hip(x0, z_scale=zs, keep_state=True)              # (B, H, W) fp16
+        with stage("hifigan_fwd"):
+            wav = vocoder.forward(mel)                                         # (B, Lfull) fp32
+        with stage("operator_mel_loss_fwd_bwd"):
+            loss, dwav = self.operator.guidance(wav, length, measurement, supervised_space, **(op_kwargs or {}))
+            if not self.per_clip_norm and loss.numel() > 1:
+                # whole-batch norm: L = sqrt(sum_b L_b^2), dL/dwav_b = (L_b / L) * dL_b/dwav_b  (device-side, B scalars)
+                total = torch.linalg.vector_norm(loss)
+                dwav.mul_((loss / total.clamp_min(1e-30))[:, None])
+                loss = total.reshape(1)
+            inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
+            L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
+                    "grad_normalize")
+        with stage("hifigan_bwd"):
+            dmel = vocoder.backward(dwav)
+        with stage("vae_bwd"):
+            g0 = vae.backward(dmel, z_scale=zs)                                # dLoss/dx0 * (1/inv_scale)
         return loss, g0, inv_scale
 
     def step(self, model_output, timestep, sample, eta=None, use_clipped_model_output=False, generator=None,
@@ -166,8 +174,10 @@ class GuidedDDIMScheduler:
         prev = torch.empty_like(x)
         x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
         grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
-        L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out), _p(grad_out),
-                                   B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1, _stream()), "sched_step")
+        with stage("sched_update"):
+            L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out), _p(grad_out),
+                                       B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1, _stream()),
+                    "sched_step")
         self.last_grad = grad_out
         if loss.numel() == 1 and self.mode != "ddim":
             loss = loss.reshape(())
@@ -175,11 +185,20 @@ class GuidedDDIMScheduler:
                                              pred_original_sample=(x0_out if x0_out is not None else x0).to(sample.dtype),
                                              loss=loss)
 
-    def optim_prompt(self, model_output, timestep, sample, encoder_hidden_states=None, encoder_hidden_states_1=None, **kwargs):
-        """Signature only: a no-op in the reference (scheduling_dps.py:63-135 discards its requires_grad clones) and
-        disabled in every shipped config (`optim_prompt: false`)."""
-        return InverseProblemSchedulerOutput(encoder_hidden_states=encoder_hidden_states,
-                                             encoder_hidden_states_1=encoder_hidden_states_1)
+    def optim_prompt(self, model_output, timestep, sample, encoder_hidden_states=None, encoder_hidden_states_1=None, eta=0.0,
+                     use_clipped_model_output=False, generator=None, variance_noise=None, return_dict=True, measurement=None,
+                     vae=None, vocoder=None, original_waveform_length=0, optim_prompt_learning_rate=1e-4,
+                     supervised_space="mel_spectrogram", *args, **kwargs):
+        """`optim_prompt` of the reference (scheduling_dps.py:63-135 and siblings): meant to be one SGD step on the prompt
+        embeddings, but the `requires_grad_` clones it makes (:93-96) are discarded and `model_output` was computed from the
+        originals, so no gradient ever reaches the embeddings -- the call returns them unchanged.  Reproduced as that no-op
+        (same signature, same output fields, same argument validation); the pipeline calls it every `t % 30 == 1` when
+        `optim_prompt=True` (pipeline_musicldm.py:710-723)."""
+        if supervised_space not in ("wav_form", "mel_spectrogram"):
+            raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
+        d = lambda v: v.detach() if v is not None else None          # noqa: E731  (the reference crashes on None here, :132)
+        return InverseProblemSchedulerOutput(encoder_hidden_states=d(encoder_hidden_states),
+                                             encoder_hidden_states_1=d(encoder_hidden_states_1))
 
 
 class DDIMScheduler(GuidedDDIMScheduler):        # scheduling_ddim.py:58-104 (the formula; the reference body crashes)

@@ -1,4 +1,4 @@
-"""-m gpu: HiFi-GAN forward + input-gradient backward (HIP, bf16 MFMA) against the fp32 oracle."""
+"""-m gpu: HiFi-GAN forward + input-gradient backward (HIP, fp16 MFMA) against the fp32 oracle."""
 import pytest
 import torch
 
