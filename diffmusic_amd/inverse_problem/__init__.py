@@ -1,6 +1,6 @@
 from .noise import GaussianNoise, PoissonNoise
 from .operator import (BaseOperator, IdentityOperator, MusicInpaintingOperator, PhaseRetrievalOperator,
-                       SuperResolutionOperator, MusicDereverberationOperator)
+                       SuperResolutionOperator, MusicDereverberationOperator, StyleGuidanceOperator)
 
 
 def get_noiser(name, sigma):                  # reference: inverse_problem/__init__.py:4-11

@@ -32,9 +32,13 @@ class SpectralFrontend:
     """dmx_audio handle: STFT(n_fft, hop) + mel filterbank, forward and hand-written backward.
     Equivalent of torchaudio MelSpectrogram(+AmplitudeToDB) / MelScale / torch.stft in the reference."""
 
-    def __init__(self, sample_rate=16000, n_fft=1024, hop_length=160, n_mels=64, window="hann"):
+    def __init__(self, sample_rate=16000, n_fft=1024, hop_length=160, n_mels=64, window="hann", fb=None):
+        """fb: optional (n_fft/2+1, n_mels) filterbank replacing the default torchaudio-style HTK one (CLAP's slaney bank)."""
         self.n_fft, self.hop, self.n_mels, self.bins = n_fft, hop_length, n_mels, n_fft // 2 + 1
-        fb = np.ascontiguousarray(dsp.melscale_fbanks(self.bins, 0.0, float(sample_rate // 2), n_mels, sample_rate))
+        if fb is None:
+            fb = dsp.melscale_fbanks(self.bins, 0.0, float(sample_rate // 2), n_mels, sample_rate)
+        fb = np.ascontiguousarray(np.asarray(fb, dtype=np.float32))
+        assert fb.shape == (self.bins, n_mels), fb.shape
         self._h = C.c_void_p(L.lib().dmx_audio_create(n_fft, hop_length, n_mels, 1 if window == "hann" else 0,
                                                        fb.ctypes.data_as(C.c_void_p)))
         if not self._h:
@@ -399,3 +403,83 @@ class MusicDereverberationOperator(_MelOperator):         # operator.py:208-250
     def _a_bwd(self, dy, full):
         n = self._h.shape[1]
         return _fir_bwd(dy, self._h, self._hrev, self._in_len, full, 1, 1, n // 2)
+
+
+class StyleGuidanceOperator(BaseOperator):                # operator.py:253-271 (unrunnable in the reference: run.py:213-214)
+    """Style guidance with BUILD-DEFINED semantics (the reference's `clap_model.get_gram_matrix`
+    does not exist anywhere): `forward(x) = noiser(x)` (identity, operator.py:270-271) and
+
+        transform(audio) = Gram(F) = F F^T / T,   F = CLAP (HTS-AT) audio-encoder token features (B, C, T) of the waveform
+
+    computed as: 16 kHz -> 48 kHz sinc-hann polyphase resampling (HIP `dmx_fir_fwd`), CLAP's log-mel front end (48 kHz,
+    n_fft 1024, hop 480, 64 slaney mel bins 0-14 kHz, power dB; HIP `dmx_audio_transform_fwd`), then the HTS-AT tower.
+    The tower is a pretrained third-party network (`transformers.ClapAudioModel`, like the text towers of the prompt front
+    end): it is WRAPPED and differentiated by torch autograd on the GPU, not re-implemented; everything around it (resampler,
+    STFT / mel and their hand-written transposes, Gram loss) is HIP.  Loss = ||G(y) - G(x_hat)||_2 per clip."""
+
+    def __init__(self, sample_rate=16000, clap_model=None, noiser=None, device="cuda", seed=0):
+        self.sample_rate, self.noiser = sample_rate, noiser
+        self.clap_sr, self.max_samples = 48000, 480000
+        kern, self.width, self.orig, self.new = dsp.sinc_resample_kernel(sample_rate, self.clap_sr)
+        self._kern_host, self._kern = torch.from_numpy(np.ascontiguousarray(kern)), None
+        from transformers.audio_utils import mel_filter_bank
+        fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=64, min_frequency=0.0, max_frequency=14000.0, sampling_rate=48000,
+                             norm="slaney", mel_scale="slaney")                    # ClapFeatureExtractor.mel_filters_slaney
+        self.frontend = SpectralFrontend(self.clap_sr, 1024, 480, 64, "hann", fb=fb)
+        if clap_model is None:                                                     # no checkpoint offline: seeded random HTS-AT
+            from transformers import ClapAudioConfig, ClapAudioModel
+            with torch.random.fork_rng(devices=[]):
+                torch.manual_seed(seed)
+                clap_model = ClapAudioModel(ClapAudioConfig())
+        self.clap = getattr(clap_model, "audio_model", clap_model).to(device).float().eval()
+        for p in self.clap.parameters():
+            p.requires_grad_(False)
+
+    def _k(self, device):
+        if self._kern is None or self._kern.device != device:
+            self._kern = self._kern_host.to(device)
+        return self._kern
+
+    def forward(self, data, **kwargs):
+        data = _as_f32_cuda(data)
+        return self.noiser(data) if self.noiser is not None else data
+
+    def _features(self, wav, length):
+        """(B, >= length) fp32 cuda -> CLAP input features (B, 1, frames, 64) (HIP) and the 48 kHz length."""
+        n48 = int(math.ceil(self.new * length / self.orig))
+        x48 = _fir_fwd(wav, length, self._k(wav.device), n48, self.orig, self.new, self.width)
+        mel = self.frontend.transform_fwd(x48, n48, True, True)                    # (B, frames, 64) log-mel dB
+        return mel[:, None], n48
+
+    def _gram(self, feats):
+        f = self.clap(input_features=feats, is_longer=None, return_dict=True).last_hidden_state.flatten(2)   # (B, C, T)
+        return torch.bmm(f, f.transpose(1, 2)) / f.shape[2]
+
+    @torch.no_grad()
+    def transform(self, audio):
+        audio = _as_f32_cuda(audio)
+        feats, _ = self._features(audio.contiguous(), audio.shape[-1])
+        return self._gram(feats)
+
+    def guidance(self, wav, length, measurement, supervised_space):
+        y = wav                                                                    # forward = identity on the vocoder output
+        if supervised_space == "wav_form":
+            m32 = self._ref(measurement, "wav_form", lambda m: m.reshape(m.shape[0], -1).contiguous())
+            yl = torch.empty(wav.shape[0], length, dtype=torch.float32, device=wav.device)
+            L.check(L.lib().dmx_mask_apply(_p(wav), wav.stride(0), None, _p(yl), length, wav.shape[0], length, length, _stream()), "copy")
+            loss, dy = l2_loss(m32, yl)
+            d = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)
+            d[:, :length] = dy
+            return loss, d
+        if supervised_space != "mel_spectrogram":
+            raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
+        ref = self._ref(measurement, "mel_spectrogram", lambda m: self.transform(m.reshape(m.shape[0], -1)))
+        feats, n48 = self._features(y, length)
+        with torch.enable_grad():
+            fg = feats.detach().requires_grad_(True)
+            diff = (ref - self._gram(fg)).flatten(1)
+            loss = torch.linalg.vector_norm(diff, dim=1)                            # per-clip Frobenius norm
+            (dfeat,) = torch.autograd.grad(loss.sum(), fg)
+        dx48 = self.frontend.transform_bwd(dfeat[:, 0].contiguous())              # (B, n48)
+        dwav = _fir_bwd(dx48, self._k(wav.device), None, length, wav.shape[1], self.orig, self.new, self.width)
+        return loss.detach(), dwav

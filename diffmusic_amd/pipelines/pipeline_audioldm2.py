@@ -1,8 +1,9 @@
 """AudioLDM2 pipeline facade (reference: diffmusic/pipelines/plpeline_audioldm2.py:924-1254).  Same loop as MusicLDM
 (the reference's two loops differ only in conditioning, :1147-1154, and in the default guidance_scale 3.5, :930);
 the U-Net attends two contexts: `generated_prompt_embeds` (B, 8, 768) from GPT-2 and `prompt_embeds` (B, L, 1024) from
-T5 with `attention_mask`.  The text / projection / GPT-2 front end is out of scope: pass the embeddings directly, as the
-reference signature allows."""
+T5 with `attention_mask`.  Pass the embeddings directly, as the reference signature allows, or attach the wrapped
+CLAP / T5 / projection / GPT-2 front end (`pipe.text_frontend = AudioLDM2PromptFrontEnd(...)`, prompt_audioldm2.py) and
+call with `prompt=` (and `prompt_type="clap"` for the audio-conditioned ablation, :469-481)."""
 import torch
 
 from ..engine import UNET_AUDIOLDM2_DEFAULT
@@ -16,7 +17,8 @@ class AudioLDM2Pipeline(MusicLDMPipeline):
     def _prepare_cond(self, prompt_embeds, negative_prompt_embeds, n_per, do_cfg, device, generated_prompt_embeds=None,
                       negative_generated_prompt_embeds=None, attention_mask=None, negative_attention_mask=None, **_):
         if generated_prompt_embeds is None:
-            raise NotImplementedError("the GPT-2 front end is out of scope: pass generated_prompt_embeds (B, 8, 768)")
+            raise NotImplementedError("no prompt front end attached: pass prompt_embeds (B, L, 1024) + generated_prompt_embeds (B, 8, 768), "
+                                      "or set pipe.text_frontend = AudioLDM2PromptFrontEnd(...) to use `prompt=`")
 
         def rep(x):
             return None if x is None else x.to(device=device, dtype=torch.float32).repeat_interleave(n_per, dim=0)
@@ -45,6 +47,15 @@ class AudioLDM2Pipeline(MusicLDMPipeline):
                  negative_prompt=None, num_waveforms_per_prompt=1, eta=0.0, generator=None, latents=None, prompt_embeds=None,
                  negative_prompt_embeds=None, generated_prompt_embeds=None, negative_generated_prompt_embeds=None,
                  attention_mask=None, negative_attention_mask=None, max_new_tokens=None, **kw):
+        if prompt_embeds is None and prompt is not None and getattr(self, "text_frontend", None) is not None:
+            enc = self.text_frontend.encode(prompt, negative_prompt, guidance_scale > 1.0, max_new_tokens=max_new_tokens,
+                                            prompt_type=kw.get("prompt_type"), measurement=kw.get("measurement"),
+                                            transcription=transcription)                  # plpeline_audioldm2.py:1077-1090
+            prompt_embeds, attention_mask, generated_prompt_embeds = (enc["prompt_embeds"], enc["attention_mask"],
+                                                                      enc["generated_prompt_embeds"])
+            if negative_prompt_embeds is None and "negative_prompt_embeds" in enc:
+                negative_prompt_embeds, negative_attention_mask, negative_generated_prompt_embeds = (
+                    enc["negative_prompt_embeds"], enc["negative_attention_mask"], enc["negative_generated_prompt_embeds"])
         self._extra_cond = dict(generated_prompt_embeds=generated_prompt_embeds,
                                 negative_generated_prompt_embeds=negative_generated_prompt_embeds,
                                 attention_mask=attention_mask, negative_attention_mask=negative_attention_mask)

@@ -87,3 +87,39 @@ def resample(wav, orig_freq, new_freq):
     y = y.transpose(1, 2).reshape(B, -1)
     target = int(math.ceil(new * L / orig))
     return y[:, :target]
+
+
+def mel_filter_bank_slaney(n_freqs=513, n_mels=64, f_min=0.0, f_max=14000.0, sample_rate=48000):
+    """librosa.filters.mel(htk=False, norm='slaney') == transformers ClapFeatureExtractor.mel_filters_slaney -> (n_freqs, n_mels).
+    Slaney mel scale: linear below 1 kHz (3 mel per 200 Hz), logarithmic above; area-normalised triangles."""
+    def hz_to_mel(f):
+        f = torch.as_tensor(f, dtype=torch.float64)
+        lin = 3.0 * f / 200.0
+        log = 15.0 + torch.log(f.clamp_min(1e-10) / 1000.0) * (27.0 / math.log(6.4))
+        return torch.where(f >= 1000.0, log, lin)
+
+    def mel_to_hz(m):
+        lin = 200.0 * m / 3.0
+        log = 1000.0 * torch.exp((math.log(6.4) / 27.0) * (m - 15.0))
+        return torch.where(m >= 15.0, log, lin)
+    fft_freqs = torch.linspace(0, sample_rate // 2, n_freqs, dtype=torch.float64)
+    m_pts = torch.linspace(float(hz_to_mel(f_min)), float(hz_to_mel(f_max)), n_mels + 2, dtype=torch.float64)
+    f_pts = mel_to_hz(m_pts)
+    f_diff = f_pts[1:] - f_pts[:-1]
+    slopes = f_pts[None, :] - fft_freqs[:, None]
+    down = -slopes[:, :-2] / f_diff[:-1]
+    up = slopes[:, 2:] / f_diff[1:]
+    fb = torch.clamp(torch.min(down, up), min=0.0)
+    enorm = 2.0 / (f_pts[2:n_mels + 2] - f_pts[:n_mels])
+    return (fb * enorm[None, :]).to(torch.float32)
+
+
+def clap_log_mel(wav48, fb=None):
+    """transformers ClapFeatureExtractor._np_extract_fbank_features (truncation != 'fusion'): periodic hann(1024), hop 480,
+    centre / reflect, power spectrogram -> slaney mel -> 10 log10(max(., 1e-10)).  (B, L) -> (B, frames, 64)."""
+    fb = mel_filter_bank_slaney() if fb is None else fb
+    window = torch.hann_window(1024, periodic=True, dtype=wav48.dtype, device=wav48.device)
+    spec = torch.stft(wav48, n_fft=1024, hop_length=480, win_length=1024, window=window, center=True, pad_mode="reflect",
+                      normalized=False, onesided=True, return_complex=True).abs() ** 2                       # (B, 513, T)
+    mel = torch.matmul(spec.transpose(1, 2), fb.to(spec))                                                        # (B, T, 64)
+    return 10.0 * torch.log10(torch.clamp(mel, min=1e-10))

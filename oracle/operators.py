@@ -131,3 +131,24 @@ class MusicDereverberationOperator(BaseOperator):     # operator.py:208-250
         ir = ir.to(data.device)
         out = F.conv1d(data.unsqueeze(1).float(), ir.unsqueeze(1), padding=ir.size(1) // 2).squeeze(1)
         return self.noiser(out)
+
+
+class StyleGuidanceOperator(BaseOperator):            # operator.py:253-271; semantics defined by the build
+    """transform(audio) = Gram(F) = F F^T / T of the CLAP (HTS-AT) audio-encoder token features F (B, C, T):
+    16 -> 48 kHz sinc-hann resampling, CLAP log-mel (audio.clap_log_mel), transformers ClapAudioModel, all fp32 eager.
+    **Parity unpinned**: the reference's `clap_model.get_gram_matrix` is undefined and run.py:213-214 raises for this task."""
+
+    def __init__(self, sample_rate=16000, clap_model=None, noiser=None):
+        self.sample_rate, self.noiser = sample_rate, noiser
+        self.clap = getattr(clap_model, "audio_model", clap_model)
+        self.fb = audio.mel_filter_bank_slaney()
+
+    def forward(self, data, **k):
+        return self.noiser(data) if self.noiser is not None else data
+
+    def features(self, a):
+        return audio.clap_log_mel(audio.resample(a.float(), self.sample_rate, 48000), self.fb)[:, None]
+
+    def transform(self, a):
+        f = self.clap(input_features=self.features(a), is_longer=None, return_dict=True).last_hidden_state.flatten(2)
+        return torch.bmm(f, f.transpose(1, 2)) / f.shape[2]

@@ -1,7 +1,7 @@
 """-m gpu: teacher-forced HIP-vs-oracle parity at PRODUCTION size and width: one 10 s clip (latent 8 x 250 x 16, mel 1000 x 64,
 160 032 samples), the benchmark architectures (HIFIGAN_DEFAULT / VAE_DEFAULT / UNET_*_DEFAULT), one test per GPU config of
 BASELINE.json: configs[1] MusicLDM + DPS inpainting, configs[2] AudioLDM2 + DSG phase retrieval, configs[3] MusicLDM + MPGD
-SR x4.  The reference step being matched is diffmusic/schedulers/scheduling_dps.py:137-219 (and siblings), restated in
+SR x4, configs[4] AudioLDM2 + DiffMusic style guidance (CLAP Gram loss, build-defined semantics).  The reference step being matched is diffmusic/schedulers/scheduling_dps.py:137-219 (and siblings), restated in
 oracle/schedulers.py on fp32 eager torch + autograd (about 2 s per clip-step on the GPU box's 16 host threads).
 
 Every stage is compared on the SAME input as the oracle stage (teacher-forced per stage) and the whole step once more end to
@@ -32,7 +32,7 @@ def _cos(a, b):
 
 def _oracle_nets(pipe, wl):
     from oracle import models as OM
-    if wl == "dsg_phase_audioldm2":
+    if "audioldm2" in wl:
         ru = OM.UNetMusicLDM(class_embed_dim=0, attn_cross_dims=(None, 768, 1024)).eval()
     else:
         ru = OM.UNetMusicLDM().eval()
@@ -43,9 +43,12 @@ def _oracle_nets(pipe, wl):
     return ru, rv, rh
 
 
-def _oracle_op(task):
+def _oracle_op(task, op=None):
+    import copy
     from oracle import operators as OO
     n = OO.get_noiser("gaussian", 0.0)
+    if task == "style_guidance":                          # same (seeded random) HTS-AT weights as the HIP operator's tower
+        return OO.StyleGuidanceOperator(16000, clap_model=copy.deepcopy(op.clap).cpu().float().eval(), noiser=n)
     if task == "music_inpainting":
         return OO.MusicInpaintingOperator(10, 16000, "box", 2, 3, 0.3, 0.1, 1.0, noiser=n)
     if task == "phase_retrieval":
@@ -54,7 +57,7 @@ def _oracle_op(task):
 
 
 # workload -> tolerances on (eps, mel, wav, loss, cos(grad), prev)
-CASES = {"dps_inpainting": 60, "dsg_phase_audioldm2": 100, "mpgd_sr4": 140}
+CASES = {"dps_inpainting": 60, "dsg_phase_audioldm2": 100, "mpgd_sr4": 140, "diffmusic_style_audioldm2": 250}
 
 
 @pytest.mark.parametrize("wl", sorted(CASES))
@@ -70,9 +73,9 @@ def test_fullsize_teacher_forced_step(wl):
     sched = pipe.scheduler
     t = sched._timesteps_host[CASES[wl]]
     ru, rv, rh = _oracle_nets(pipe, wl)
-    rop = _oracle_op(task)
+    rop = _oracle_op(task, op)
     rs = OS.get_scheduler(sname)(operator=rop, **bench.SCHED_CFG)
-    rs.set_timesteps(bench.N_STEPS)
+    rs.set_timesteps(bench.WORKLOAD_STEPS.get(wl, bench.N_STEPS))
     rep = {"workload": wl, "timestep": t}
 
     # ---- measurement operator on the same clip
@@ -152,7 +155,7 @@ def test_fullsize_teacher_forced_step(wl):
     assert rep["unet_eps"] < 1e-2, rep
     assert rep["vae_mel"] < 1e-2, rep
     assert rep["vocoder_wav"] < 1e-2, rep
-    assert rep["operator_loss"] < 1e-3 and rep["operator_bwd"] < 1e-2, rep
+    assert rep["operator_loss"] < 2e-3 and rep["operator_bwd"] < 2e-2, rep
     assert rep["step_loss"] < 1e-2, rep
     assert rep["step_prev_sample"] < 1e-2, rep
     assert rep["vae_bwd_cos"] > 0.99 and rep["vocoder_bwd_cos"] > 0.97 and rep["step_grad_cos"] > 0.97, rep
