@@ -1,0 +1,94 @@
+"""Dataset crop / resample loader (reference: diffmusic/data/dataloader.py:15-89): the same
+registry (`register_dataset`, `get_dataset(name, type, root, **kw)`, `get_dataloader`) and the `wav` dataset -- mono mix-down,
+resampling to `sample_rate`, optional transform, crop to [start_s, end_s), item = (waveform, file name).
+
+torchaudio / pydub are absent from this image: WAV files are decoded with the standard library (`wave`: 8/16/24/32-bit PCM)
+or scipy (float WAVs), and resampling uses the same sinc-hann polyphase kernel as the measurement operators
+(torchaudio `Resample` semantics; host side -- the loader runs before the hot loop).  The `mp3`
+dataset of the reference needs pydub / ffmpeg and is not provided."""
+import os
+import wave as _wave
+from glob import glob
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+from ..pipelines.prompt_audioldm2 import resample_to
+
+__DATASET__ = {}
+
+
+def register_dataset(name):
+    def wrapper(cls):
+        if __DATASET__.get(name, None):
+            raise NameError(f"Name {name} is already registered!")
+        __DATASET__[name] = cls
+        return cls
+    return wrapper
+
+
+def get_dataset(name, type, root, **kwargs):
+    if __DATASET__.get(type, None) is None:
+        raise NameError(f"Dataset {type} is not defined.")
+    return __DATASET__[type](root=root, **kwargs)
+
+
+def get_dataloader(dataset, batch_size, num_workers, train):
+    return DataLoader(dataset, batch_size, shuffle=train, num_workers=num_workers, drop_last=train)
+
+
+def load_wav(path):
+    """-> (float32 tensor (channels, time) in [-1, 1], sample_rate), like torchaudio.load(path)."""
+    try:
+        with _wave.open(path, "rb") as w:
+            ch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+            raw = w.readframes(n)
+        if width == 1:
+            x = (np.frombuffer(raw, dtype=np.uint8).astype(np.float32) - 128.0) / 128.0
+        elif width == 2:
+            x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        elif width == 3:
+            b = np.frombuffer(raw, dtype=np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            x = (v - ((v & 0x800000) << 1)).astype(np.float32) / 8388608.0
+        elif width == 4:
+            x = np.frombuffer(raw, dtype="<i4").astype(np.float32) / 2147483648.0
+        else:
+            raise ValueError(f"unsupported sample width {width}")
+        x = x.reshape(-1, ch).T
+    except _wave.Error:                                   # IEEE-float WAV: the wave module refuses it
+        from scipy.io import wavfile
+        sr, data = wavfile.read(path)
+        data = np.asarray(data)
+        if data.dtype.kind == "i":
+            data = data.astype(np.float32) / float(np.iinfo(data.dtype).max + 1)
+        elif data.dtype.kind == "u":
+            data = (data.astype(np.float32) - 128.0) / 128.0
+        x = np.atleast_2d(data.astype(np.float32).T if data.ndim == 2 else data.astype(np.float32))
+    return torch.from_numpy(np.ascontiguousarray(x)), int(sr)
+
+
+@register_dataset(name="wav")
+class WAVDataset(Dataset):                                  # dataloader.py:47-89
+    def __init__(self, root, sample_rate, audio_length_in_s, start_s=0, end_s=0, transforms=None):
+        self.root, self.sample_rate, self.audio_length_in_s = root, sample_rate, audio_length_in_s
+        self.start_s, self.end_s, self.transforms = start_s, end_s, transforms
+        self.fpaths = sorted(glob(root + "/**/*.wav", recursive=True))
+        assert len(self.fpaths) > 0, "File list is empty. Check the root."
+
+    def __len__(self):
+        return len(self.fpaths)
+
+    def __getitem__(self, index):
+        fpath = self.fpaths[index]
+        wave, sr = load_wav(fpath)                          # (channels, time)
+        if wave.size(0) > 1:
+            wave = wave.mean(dim=0, keepdim=True)
+        if sr != self.sample_rate:
+            wave = resample_to(wave, sr, self.sample_rate)
+        if self.transforms is not None:
+            wave = self.transforms(wave)
+        wave = wave[0]
+        gt_wave = wave[int(self.start_s * self.sample_rate): int(self.end_s * self.sample_rate)]
+        return gt_wave, os.path.basename(fpath)

@@ -50,16 +50,20 @@ def build_operator(task, cfg, mask_type):
     return op, scale
 
 
-def load_clips(paths, n, sr, length, seed):
-    """(B, length) fp32 in [-1, 1]: 16-bit / float wav files at `sr` (cropped or zero-padded), or seeded synthetic chords."""
+def load_clips(paths, n, sr, length, seed, start_s=0.0):
+    """(B, length) fp32 in [-1, 1]: wav files decoded, mixed down to mono and resampled to `sr` by the dataset loader
+    (diffmusic_amd/data/dataloader.py; reference dataloader.py:47-89), cropped from `start_s` / zero-padded to `length`;
+    seeded synthetic chords fill up to `n`."""
+    from diffmusic_amd.data.dataloader import load_wav
+    from diffmusic_amd.pipelines.prompt_audioldm2 import resample_to
     clips = []
     for p in paths:
-        rate, x = scipy.io.wavfile.read(p)
+        x, rate = load_wav(p)
+        x = x.mean(dim=0, keepdim=True)
         if rate != sr:
-            raise ValueError(f"{p}: sample rate {rate}, expected {sr} (resample offline; the reference uses resampy, dataloader.py:47-89)")
-        x = x.astype(np.float32) / (32768.0 if x.dtype == np.int16 else 1.0)
-        x = x.mean(axis=1) if x.ndim == 2 else x
-        clips.append(torch.from_numpy(np.pad(x[:length], (0, max(0, length - len(x))))))
+            x = resample_to(x, rate, sr)
+        x = x[0, int(start_s * sr):][:length]
+        clips.append(torch.nn.functional.pad(x, (0, max(0, length - x.numel()))))
     g = torch.Generator().manual_seed(seed)
     while len(clips) < n:
         f = 110.0 * 2 ** (torch.randint(0, 36, (4,), generator=g).float() / 12)
@@ -77,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument("--mask_type", default="box", choices=["box", "random", "periodic"])
     ap.add_argument("--supervised_space", default="mel_spectrogram")
     ap.add_argument("--weights", default="synthetic", help="checkpoint directory with {unet,vae,vocoder}/*.safetensors, or 'synthetic'")
-    ap.add_argument("--wav", nargs="*", default=[], help="input clips (mono, 16 kHz); synthetic clips fill up to --batch")
+    ap.add_argument("--wav", nargs="*", default=[], help="input clips (any PCM / float wav: mixed to mono and resampled to the data sample rate); synthetic clips fill up to --batch")
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--prompt_embeds", default=None, help=".npy with (B, 512) text embeddings (MusicLDM)")
     ap.add_argument("--num_inference_steps", type=int, default=None)
