@@ -93,6 +93,7 @@ _SIGS = {
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_destroy": (None, [C.c_void_p]),
     "dmx_audio_num_frames": (C.c_int, [C.c_void_p, C.c_int]),
+    "dmx_audio_num_bins": (C.c_int, [C.c_void_p]),
     "dmx_audio_state_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     "dmx_audio_transform_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_float, C.c_float, C.c_void_p]),
@@ -108,6 +109,7 @@ _SIGS = {
     "dmx_fir_bwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_void_p]),
     "dmx_sched_pred_x0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
     "dmx_sched_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_randn_philox": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_ulonglong), C.c_ulonglong, C.c_void_p]),
     "dmx_sched_step": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),
 }
 

@@ -73,5 +73,33 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+TORCH_OPS_SRC = os.path.join(HERE, "csrc_torch", "torch_ops.cpp")
+TORCH_OPS_LIB = os.path.join(HERE, "lib", "libdiffmusic_torch_ops.so")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """libdiffmusic_torch_ops.so: TORCH_LIBRARY(diffmusic_hip) wrappers over the C ABI (csrc_torch/torch_ops.cpp).  Host code
+    only (the kernels live in libdiffmusic_hip.so, which it links), so it is compiled with g++ against torch's headers."""
+    import torch
+    lib = build_library(force=False, verbose=verbose)
+    hdr = os.path.join(os.path.dirname(HERE), "include", "diffmusic_hip.h")
+    if not (force or _stale(TORCH_OPS_LIB, [TORCH_OPS_SRC, hdr, lib])):
+        return TORCH_OPS_LIB
+    tdir = os.path.dirname(torch.__file__)
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-w",
+           f"-I{tdir}/include", f"-I{tdir}/include/torch/csrc/api/include", f"-I{rocm}/include", TORCH_OPS_SRC, "-o", TORCH_OPS_LIB,
+           f"-L{os.path.dirname(lib)}", "-ldiffmusic_hip", f"-L{tdir}/lib", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip",
+           "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building the torch op library failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    return TORCH_OPS_LIB
+
+
 if __name__ == "__main__":
     print(build_library(force="--force" in sys.argv, verbose=True))
+    print(build_torch_ops(force="--force" in sys.argv, verbose=True))

@@ -43,6 +43,7 @@ void dmx_audio_destroy(dmx_audio* a) {
   delete a;
 }
 int dmx_audio_num_frames(const dmx_audio* a, int L) { return frames_of(a, L); }
+int dmx_audio_num_bins(const dmx_audio* a) { return a->bins; }
 size_t dmx_audio_state_bytes(const dmx_audio* a, int batch, int L) {
   const size_t M = (size_t)batch * frames_of(a, L);
   return 4 * (align_up(M * a->Npad, 64) + align_up(M * a->n_mels, 64) + align_up(M * a->Kpad, 64) + align_up(M * a->n_fft, 64));

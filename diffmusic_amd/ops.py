@@ -1,0 +1,43 @@
+"""PyTorch-ROCm custom ops `torch.ops.diffmusic_hip.*`: TORCH_LIBRARY wrappers over the C ABI,
+compiled from csrc_torch/torch_ops.cpp into lib/libdiffmusic_torch_ops.so and loaded with `torch.ops.load_library`.
+
+    from diffmusic_amd import ops
+    prev, x0 = ops.hip.sched_update(1, x, eps, x0, g0, inv_scale, None, a_t, a_p, sigma, rate, 1e-8, False)
+
+The facades (`Scheduler.step`, `Pipeline.__call__`, the operators) may call either this layer or the ctypes binding of the
+same entry points (`_lib.py`); both end in the same `extern "C"` launchers on torch's current HIP stream.  The scheduler
+arithmetic of the facade (x0 prediction, CFG combine, fused update) goes through this layer by default; DMX_TORCH_OPS=0
+switches those three calls to the ctypes binding.  No CPU fallback: a missing library raises."""
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiffmusic_torch_ops.so")
+USE_TORCH_OPS = os.environ.get("DMX_TORCH_OPS", "1") not in ("", "0")
+_loaded = False
+
+OP_NAMES = ("sched_pred_x0", "cfg_combine", "sched_update", "randn_philox", "mask_mul", "l2norm", "resample_fwd", "resample_bwd",
+            "logmel_fwd", "logmel_bwd", "stft_mag_fwd", "stft_mag_bwd", "melscale_fwd", "unet_fwd", "vae_dec_fwd", "vae_dec_bwd",
+            "hifigan_fwd", "hifigan_bwd")
+
+
+def load():
+    """Loads the op library once (raises if it is missing: build it with `python -m diffmusic_amd.build`)."""
+    global _loaded
+    if not _loaded:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m diffmusic_amd.build` (no CPU fallback)")
+        from . import _lib
+        _lib.lib()                                   # libdiffmusic_hip.so first (the op library links it by rpath $ORIGIN)
+        torch.ops.load_library(LIB_PATH)
+        _loaded = True
+    return torch.ops.diffmusic_hip
+
+
+class _Hip:
+    def __getattr__(self, name):
+        return getattr(load(), name)
+
+
+hip = _Hip()

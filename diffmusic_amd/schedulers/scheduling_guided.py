@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from ..torch_utils import randn_tensor
+from .. import ops
+from ..torch_utils import randn_tensor, randn_philox
 from ..profiling import stage
 from .utils import InverseProblemSchedulerOutput
 
@@ -40,7 +41,8 @@ class GuidedDDIMScheduler:
     def __init__(self, operator=None, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
                  thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
-                 timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, per_clip_norm=True, *args, **kwargs):
+                 timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, per_clip_norm=True, device_noise=False,
+                 *args, **kwargs):
         if prediction_type != "epsilon" or clip_sample or thresholding or rescale_betas_zero_snr:
             raise NotImplementedError("only epsilon prediction without clipping/thresholding (the reference's configs) is built")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
@@ -71,6 +73,11 @@ class GuidedDDIMScheduler:
         self.per_clip_norm = per_clip_norm
         self.last_grad = None
         self.debug_keep_grad = False
+        # False (default): per-step noise comes from `randn_tensor` (host generators, uploaded), bit-identical to the reference's
+        # stream.  True: drawn on the device by the Philox kernel (csrc/rng.hip), keyed per clip by the generators' initial seeds
+        # -- a different (but equally per-clip, GPU-count-independent) stream, without the host draw and the H2D copy.
+        self.device_noise = device_noise
+        self._noise_offset = 0
 
     # ---- protocol pieces the pipelines touch
     def scale_model_input(self, sample, timestep=None):
@@ -92,6 +99,7 @@ class GuidedDDIMScheduler:
         else:
             raise ValueError(f"{sp} is not supported")
         self._timesteps_host = [int(t) for t in ts]
+        self._noise_offset = 0
         if self.operator is not None and hasattr(self.operator, "reset_cache"):
             self.operator.reset_cache()           # a new trajectory: forget the cached transform(measurement)
         self.timesteps = torch.from_numpy(ts).to(device) if device is not None else torch.from_numpy(ts)
@@ -149,8 +157,11 @@ class GuidedDDIMScheduler:
         e = model_output.detach().to(torch.float32).contiguous()
         B, n = x.shape[0], x[0].numel()
         lib = L.lib()
-        x0 = torch.empty_like(x)
-        L.check(lib.dmx_sched_pred_x0(_p(x), _p(e), _p(x0), x.numel(), a_t, _stream()), "pred_x0")
+        if ops.USE_TORCH_OPS:
+            x0 = ops.hip.sched_pred_x0(x, e, a_t)                  # torch.ops.diffmusic_hip.* (csrc_torch/torch_ops.cpp)
+        else:
+            x0 = torch.empty_like(x)
+            L.check(lib.dmx_sched_pred_x0(_p(x), _p(e), _p(x0), x.numel(), a_t, _stream()), "pred_x0")
         mode = _MODE[self.mode]
         noise = None
         if self.mode in ("dps", "mpgd") and eta > 0:
@@ -168,22 +179,42 @@ class GuidedDDIMScheduler:
                                                  kwargs.get("op_kwargs"))
             if self.mode in ("dsg", "diffmusic"):
                 sn = kwargs.get("sample_noise")
-                if sn is None:
+                if sn is None and self.device_noise:
+                    sn = self._philox_noise(model_output.shape, generator, model_output.device)
+                elif sn is None:
                     sn = randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
                 noise = sn.to(torch.float32).contiguous()
-        prev = torch.empty_like(x)
-        x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
         grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
-        with stage("sched_update"):
-            L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out), _p(grad_out),
-                                       B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1, _stream()),
-                    "sched_step")
+        if ops.USE_TORCH_OPS and grad_out is None:
+            with stage("sched_update"):
+                prev, x0_u = ops.hip.sched_update(mode, x, e, x0, g0, inv_scale, noise, a_t, a_p, sigma, float(rate), float(eps),
+                                                  not self.per_clip_norm)
+            x0_out = x0_u if self.mode == "mpgd" else None
+        else:
+            prev = torch.empty_like(x)
+            x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
+            with stage("sched_update"):
+                L.check(lib.dmx_sched_step(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out),
+                                           _p(grad_out), B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1,
+                                           _stream()), "sched_step")
         self.last_grad = grad_out
         if loss.numel() == 1 and self.mode != "ddim":
             loss = loss.reshape(())
         return InverseProblemSchedulerOutput(prev_sample=prev.to(sample.dtype),
                                              pred_original_sample=(x0_out if x0_out is not None else x0).to(sample.dtype),
                                              loss=loss)
+
+    def _philox_noise(self, shape, generator, device):
+        gens = generator if isinstance(generator, (list, tuple)) else [generator] * shape[0]
+        if any(g is None for g in gens):
+            raise ValueError("device_noise=True needs generator(s): their initial seeds key the per-clip Philox streams")
+        seeds = [int(g.initial_seed()) + (0 if isinstance(generator, (list, tuple)) else i) for i, g in enumerate(gens)]
+        n = 1
+        for d in shape[1:]:
+            n *= int(d)
+        out = randn_philox(shape, seeds, self._noise_offset, device)
+        self._noise_offset += (n + 3) // 4
+        return out
 
     def optim_prompt(self, model_output, timestep, sample, encoder_hidden_states=None, encoder_hidden_states_1=None, eta=0.0,
                      use_clipped_model_output=False, generator=None, variance_noise=None, return_dict=True, measurement=None,

@@ -130,6 +130,7 @@ typedef struct dmx_audio dmx_audio;
 dmx_audio* dmx_audio_create(int n_fft, int hop, int n_mels, int window_hann, const float* fb_host);
 void dmx_audio_destroy(dmx_audio* a);
 int dmx_audio_num_frames(const dmx_audio* a, int L);
+int dmx_audio_num_bins(const dmx_audio* a); /* n_fft / 2 + 1 */
 size_t dmx_audio_state_bytes(const dmx_audio* a, int batch, int L);
 /* wav (B, L) fp32 (row stride wav_stride) -> mel_out (B, frames, n_mels) fp32.  power2: |X|^2 (1) or |X| (0);
  * to_db: 10*log10(max(.,1e-10)); then clamp(lo, hi).  `state` keeps the spectrum for the backward call. */
@@ -179,6 +180,12 @@ int dmx_sched_cfg_combine(const float* eps2, float* out, long long n, float scal
 int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
                    const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
                    float sigma, float rate, float eps_small, int global_norm, void* stream);
+
+/* Device-side N(0,1) noise, Philox4x32-10 + Box-Muller (csrc/rng.hip): optional replacement for the host draw + upload of
+ * randn_tensor (diffmusic/torch_utils.py:31-76) that DSG / DiffMusic pay every step (scheduling_dsg.py:215).  out (batch, n)
+ * fp32; clip b uses key seeds_host[b] (HOST array of `batch` <= 64 values); element i = normal (i & 3) of Philox block
+ * offset + i / 4, so a draw depends only on (seed_b, offset, i) -- not on the batch composition or the number of GPUs. */
+int dmx_randn_philox(float* out, int batch, long long n, const unsigned long long* seeds_host, unsigned long long offset, void* stream);
 
 /* ---- measurement hooks: HIP events around every implicit-GEMM launch (bench.py roofline leg) ---------- */
 void dmx_prof_begin(void);

@@ -52,3 +52,26 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_torch_op_library_loads_and_registers_every_stage_op(monkeypatch, tmp_path):
+    """TORCH_LIBRARY(diffmusic_hip) layer: builds, loads without a GPU, registers all stage ops, fails
+    loudly when the library is missing, and refuses CPU tensors (no CPU fallback)."""
+    import pytest
+    import torch
+    from diffmusic_amd.build import build_torch_ops
+    from diffmusic_amd import ops
+    assert os.path.exists(build_torch_ops())
+    h = ops.load()
+    for name in ops.OP_NAMES:
+        assert hasattr(h, name), name
+        assert str(getattr(h, name).default._schema).startswith(f"diffmusic_hip::{name}(")
+    for want in ("unet_fwd", "vae_dec_fwd", "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "logmel_fwd", "logmel_bwd", "stft_mag_fwd",
+                 "stft_mag_bwd", "melscale_fwd", "resample_fwd", "resample_bwd", "mask_mul", "l2norm", "sched_update", "randn_philox"):
+        assert want in ops.OP_NAMES                                   # the op list of SURVEY.md section 8b.4
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        h.sched_pred_x0(torch.zeros(2, 4), torch.zeros(2, 4), 0.5)
+    monkeypatch.setattr(ops, "_loaded", False)
+    monkeypatch.setattr(ops, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.load()

@@ -135,3 +135,24 @@ def test_nan_retry_with_real_engines():
     assert pipe.nan_restarts == 1 and state["calls"] == 3 + N
     assert len(state["first"]) == 2 and not torch.equal(state["first"][0], state["first"][1])
     assert out.audios.shape == (B, L_) and np.isfinite(out.audios).all()
+
+
+def test_device_philox_noise_matches_numpy_restatement():
+    """csrc/rng.hip vs oracle/rng.py (Philox4x32-10 known-answer vectors are checked on the CPU side): values to 2e-5 (fp32
+    log / sin / cos), per-clip keys, offset continuation, and the DSG scheduler's device_noise option."""
+    from diffmusic_amd.torch_utils import randn_philox
+    from oracle.rng import randn_philox as ref_philox
+    shape = (3, 8, 25, 16)
+    n = 8 * 25 * 16
+    seeds = [0, 1234, 2 ** 40 + 7]
+    a = randn_philox(shape, seeds, 0, "cuda").cpu().reshape(3, -1).double().numpy()
+    for b, sd in enumerate(seeds):
+        assert np.abs(a[b] - ref_philox(n, sd, 0)).max() < 2e-5
+    off = (n + 3) // 4
+    b2 = randn_philox(shape, seeds, off, "cuda").cpu().reshape(3, -1).double().numpy()
+    both = ref_philox(2 * n, seeds[1], 0)
+    assert np.abs(b2[1] - both[n:]).max() < 2e-5                       # the second draw continues the clip's stream
+    big = randn_philox((2, 1, 1, 400001), [5, 6], 0, "cuda")            # odd length: scalar tail stores
+    assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3 and abs(float((big ** 4).mean()) - 3.0) < 0.05
+    one = randn_philox((1, 8, 25, 16), [1234], 0, "cuda").cpu().reshape(-1).double().numpy()
+    assert np.array_equal(one, a[1])                                   # a clip's noise does not depend on its batch

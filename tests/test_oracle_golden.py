@@ -89,3 +89,13 @@ def test_operator_fixtures(golden_dir):
     gens = [torch.Generator().manual_seed(k) for k in range(3)]
     r = randn_tensor((3, 8, 5, 4), generator=gens, device=torch.device("cpu"), dtype=torch.float32).numpy()
     assert np.array_equal(r, fx["randn_list/out"])
+
+
+def test_philox_known_answer_vectors():
+    """Random123's philox4x32-10 known-answer vectors pin the numpy restatement that the device RNG is tested against."""
+    from oracle.rng import philox4x32_10
+    kat = [([0, 0, 0, 0], (0, 0), [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, (0xffffffff, 0xffffffff), [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], (0xa4093822, 0x299f31d0), [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, want in kat:
+        assert [int(v) for v in philox4x32_10([ctr], key)[0]] == want
