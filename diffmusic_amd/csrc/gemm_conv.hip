@@ -177,7 +177,6 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(A_ISS >= 1 && B_ISS >= 1, "tile too small");
 
-  short2* s_taps = reinterpret_cast<short2*>(smem + NSTAGE * STAGE);
   constexpr int PER = A_ISS + B_ISS;              // LDS-DMA instructions per thread per stage
   constexpr int KEEP = (NSTAGE - 2) * PER;        // loads allowed in flight when the next tile must have landed
 
@@ -192,12 +191,20 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, OOB, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, OOB, 0x00020000);
 
-  if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
+  // tap table in a REGISTER: lane j (< 16) holds (dy, dx) of tap j, looked up with v_readlane / ds_bpermute.  It must not live
+  // in LDS: the compiler puts an s_waitcnt vmcnt(0) in front of every LDS read it can see (it may alias an in-flight LDS-DMA
+  // target), and a table read at the top of the K step drained the whole ring once per step -- with 3 or 4 stages only one
+  // tile was ever in flight under the MFMAs.
+  int tapreg = 0;
+#pragma unroll
+  for (int j = 0; j < DMX_MAX_TAPS; ++j)
+    if (lane == j) tapreg = (int)(unsigned char)p.tdy[j] | ((int)(unsigned char)p.tdx[j] << 8);
 
   const int lrow = lane >> 3, cc = (lane & 7) ^ lrow;   // logical 16-B chunk this lane fetches
   const int cpt = p.Ci >> 3;
   const int HqWq = p.Hq * p.Wq;
-  unsigned a_boff[A_ISS];
+  const unsigned lda2 = (unsigned)p.lda * 2u;
+  unsigned a_boff[A_ISS], a_lin[A_ISS];
   int a_iy[A_ISS], a_ix[A_ISS];
 #pragma unroll
   for (int i = 0; i < A_ISS; ++i) {
@@ -205,12 +212,14 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     if (m < p.M) {
       const int b = m / HqWq, rem = m - b * HqWq;
       const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-      a_boff[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * (unsigned)p.lda * 2u;
+      a_boff[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * lda2;
       a_iy[i] = qy * p.sy;
       a_ix[i] = qx * p.sx;
     } else {
       a_boff[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;
     }
+    // byte offset of this lane's chunk at tap (0, 0), channel group 0 (meaningless for an out-of-range row: its iy test fails)
+    a_lin[i] = a_boff[i] + (unsigned)(a_iy[i] * p.Wi + a_ix[i]) * lda2 + ((unsigned)cc << 4);
   }
   unsigned w_off[B_ISS];
 #pragma unroll
@@ -218,7 +227,6 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     const int n = tn * BN + (i * NW + wave) * 8 + lrow;
     w_off[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u : OOB;
   }
-  __syncthreads();
 
   const int kchunks = p.K >> 3;
   // K order: with Ci % 64 == 0 a K-step is one (tap, 64-channel group); walk the taps innermost so the ~(BM + halo)
@@ -228,25 +236,44 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int nk_all = (p.K + BK - 1) / BK;
   const int ks_per = (nk_all + nsplit - 1) / nsplit;
   const int ks0 = sp * ks_per, ks1 = ks0 + ks_per < nk_all ? ks0 + ks_per : nk_all;
+  // tap-inner walk without divisions: (tap, channel group) of the NEXT step to be issued; issue() is called with consecutive steps
+  int i_cg = ks0 / p.ntaps, i_tp = ks0 - i_cg * p.ntaps;
   auto issue = [&](int ksl, int stage) {
-    const int ks = ksl + ks0;
-    int kc;
+    char* sbase = smem + stage * STAGE;
     if (tap_inner) {
-      const int cg = ks / p.ntaps, tp = ks - cg * p.ntaps;
-      kc = (cg < cgroups) ? tp * cpt + cg * 8 + cc : kchunks;   // past the end -> out of range
-    } else {
-      kc = ks * 8 + cc;
+      // everything that depends on the K step is wave-uniform here: one readlane for the tap, one scalar byte delta for all rows
+      const int tp = __builtin_amdgcn_readfirstlane(i_tp), cgi = __builtin_amdgcn_readfirstlane(i_cg);
+      const bool kval = cgi < cgroups && ksl + ks0 < ks1;
+      const int tv = __builtin_amdgcn_readlane(tapreg, tp);
+      const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
+      const unsigned sdel = (unsigned)((dy * p.Wi + dx) * (int)lda2) + ((unsigned)cgi << 7);       // tap shift + 64-channel group, bytes
+      const unsigned skc = (unsigned)(tp * cpt + cgi * 8 + cc) << 4;                                  // weight-row byte offset of this chunk
+#pragma unroll
+      for (int i = 0; i < A_ISS; ++i) {
+        const bool ok = kval && (unsigned)(a_iy[i] + dy) < (unsigned)p.Hi && (unsigned)(a_ix[i] + dx) < (unsigned)p.Wi;
+        const unsigned voff = ok ? a_lin[i] + sdel : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < B_ISS; ++i) {
+        const unsigned voff = (kval && w_off[i] != OOB) ? w_off[i] + skc : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+      }
+      if (++i_tp == p.ntaps) { i_tp = 0; ++i_cg; }
+      return;
     }
+    const int ks = ksl + ks0;
+    const int kc = ks * 8 + cc;
     const int tap = kc / cpt;
     const unsigned cin2 = (unsigned)(kc - tap * cpt) << 4;      // byte offset of the chunk inside the pixel
     const bool kval = kc < kchunks && ks < ks1;
-    const short2 t = s_taps[tap & (DMX_MAX_TAPS - 1)];
-    char* sbase = smem + stage * STAGE;
+    const int tv = __builtin_amdgcn_ds_bpermute((tap & (DMX_MAX_TAPS - 1)) << 2, tapreg);
+    const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
 #pragma unroll
     for (int i = 0; i < A_ISS; ++i) {
-      const int iy = a_iy[i] + t.x, ix = a_ix[i] + t.y;
+      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
       const bool ok = kval && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const unsigned voff = ok ? a_boff[i] + (unsigned)(iy * p.Wi + ix) * (unsigned)p.lda * 2u + cin2 : OOB;
+      const unsigned voff = ok ? a_boff[i] + (unsigned)(iy * p.Wi + ix) * lda2 + cin2 : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
 #pragma unroll
