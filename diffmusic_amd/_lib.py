@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdiffmusic_hip.so")
+LIB_PATH = os.environ.get("DMX_LIB_PATH") or os.path.join(_HERE, "lib", "libdiffmusic_hip.so")   # DMX_LIB_PATH: dev A/B builds
 MAX_STAGES = 8
 
 

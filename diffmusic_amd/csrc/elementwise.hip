@@ -502,6 +502,51 @@ __global__ void transpose_kernel(const act_t* __restrict__ in, act_t* __restrict
   }
 }
 
+// Vector variant for 16-byte-granular operands (row strides, batch strides and base pointers multiples of 8 elements): 64 x 64
+// tiles, 16-B global loads along the input rows and 16-B global stores along the output rows; the element transposition goes
+// through LDS with a 66-element pitch (33 dwords: rows 8 apart fall on different banks).  Output columns past R inside the last
+// 8-wide chunk are written as zeros (the callers pad the row pitch of the transposed tensor to a multiple of 8).
+__global__ __launch_bounds__(256) void transpose64_kernel(const act_t* __restrict__ in, act_t* __restrict__ out, int R, int Cc,
+                                                          long long ldi, long long ldo, int Zi, long long sIo, long long sIi,
+                                                          long long sOo, long long sOi) {
+  __shared__ act_t tile[64][66];
+  const int z = blockIdx.z, zo = z / Zi, zi = z - zo * Zi;
+  const act_t* ib = in + zo * sIo + zi * sIi;
+  act_t* ob = out + zo * sOo + zi * sOi;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = threadIdx.x + k * 256, row = id >> 3, cc = id & 7;
+    const int r = r0 + row, c = c0 + cc * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < R && c < Cc) {
+      if (c + 8 <= Cc) {
+        v = *reinterpret_cast<const uint4*>(ib + (long long)r * ldi + c);
+      } else {
+        act_t t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = c + e < Cc ? ib[(long long)r * ldi + c + e] : (act_t)0;
+        v = make_uint4(t[0] | ((uint32_t)t[1] << 16), t[2] | ((uint32_t)t[3] << 16), t[4] | ((uint32_t)t[5] << 16), t[6] | ((uint32_t)t[7] << 16));
+      }
+    }
+    uint32_t* d = reinterpret_cast<uint32_t*>(&tile[row][cc * 8]);      // 132-byte rows: 4-byte aligned only
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int id = threadIdx.x + k * 256, orow = id >> 3, rc = id & 7;
+    const int c = c0 + orow, r = r0 + rc * 8;
+    if (c < Cc && r < R) {
+      act_t t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = tile[rc * 8 + e][orow];       // rows past R hold zeros (loaded as such)
+      *reinterpret_cast<uint4*>(ob + (long long)c * ldo + r) =
+          make_uint4(t[0] | ((uint32_t)t[1] << 16), t[2] | ((uint32_t)t[3] << 16), t[4] | ((uint32_t)t[5] << 16), t[6] | ((uint32_t)t[7] << 16));
+    }
+  }
+}
+
 // copy (rows, C) block into a wider channels-last tensor at channel offset (concat / slice)
 __global__ void copy_channels_kernel(const act_t* __restrict__ src, act_t* __restrict__ dst, long long rows,
                                      int C, int lds, int ldd, int soff, int doff) {
@@ -778,6 +823,11 @@ int dmx_upsample2x_bwd(const act_t* dy, act_t* dx, int B, int Hi, int Wi, int C,
 }
 int dmx_transpose(const act_t* in, act_t* out, int R, int C, long long ldi, long long ldo, int Z, int Zi, long long sIo,
                   long long sIi, long long sOo, long long sOi, hipStream_t st) {
+  const bool vec = !((ldi | ldo | sIo | sIi | sOo | sOi) & 7) && !(((uintptr_t)in | (uintptr_t)out) & 15) && ldo >= (long long)((R + 7) & ~7);
+  if (vec) {
+    hipLaunchKernelGGL(transpose64_kernel, dim3(cdiv(C, 64), cdiv(R, 64), Z), dim3(256), 0, st, in, out, R, C, ldi, ldo, Zi, sIo, sIi, sOo, sOi);
+    return CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32), Z), dim3(256), 0, st, in, out, R, C, ldi, ldo, Zi,
                      sIo, sIi, sOo, sOi);
   return CHECK_LAUNCH();

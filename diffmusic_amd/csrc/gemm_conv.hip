@@ -231,8 +231,9 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int kchunks = p.K >> 3;
   // K order: with Ci % 64 == 0 a K-step is one (tap, 64-channel group); walk the taps innermost so the ~(BM + halo)
   // input rows of a channel group are re-read from L2 by consecutive K-steps instead of once per pass over all channels
-  const bool tap_inner = (p.Ci & 63) == 0 && p.ntaps > 1;
-  const int cgroups = p.Ci >> 6;
+  // (single-tap GEMMs take the same division-free walk: the channel groups of their only tap, the last one possibly partial)
+  const bool tap_inner = (p.Ci & 63) == 0 || p.ntaps == 1;
+  const int cgroups = (p.Ci + 63) >> 6;
   const int nk_all = (p.K + BK - 1) / BK;
   const int ks_per = (nk_all + nsplit - 1) / nsplit;
   const int ks0 = sp * ks_per, ks1 = ks0 + ks_per < nk_all ? ks0 + ks_per : nk_all;
@@ -243,7 +244,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     if (tap_inner) {
       // everything that depends on the K step is wave-uniform here: one readlane for the tap, one scalar byte delta for all rows
       const int tp = __builtin_amdgcn_readfirstlane(i_tp), cgi = __builtin_amdgcn_readfirstlane(i_cg);
-      const bool kval = cgi < cgroups && ksl + ks0 < ks1;
+      const bool kval = cgi < cgroups && ksl + ks0 < ks1 && cgi * 8 + cc < cpt;     // (lane term: partial last group when Ci % 64 != 0)
       const int tv = __builtin_amdgcn_readlane(tapreg, tp);
       const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
       const unsigned sdel = (unsigned)((dy * p.Wi + dx) * (int)lda2) + ((unsigned)cgi << 7);       // tap shift + 64-channel group, bytes
@@ -300,8 +301,11 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
+#ifndef DMX_ISSUE_AT
+#define DMX_ISSUE_AT 0      // fragment step before which the LDS-DMA of tile ks + NSTAGE - 1 is issued (0: ahead of the fragment reads)
+#endif
   for (int ks = 0; ks < nk; ++ks) {
-    issue(ks + NSTAGE - 1, nxt);
+    if constexpr (DMX_ISSUE_AT == 0) issue(ks + NSTAGE - 1, nxt);
     const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
     const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
     {
@@ -320,7 +324,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       static_for<0, FN>([&wf0, aB0](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf0[j], aB0, j * 2048); });
       DMX_DSR(af[0], aA0, 0);
       if constexpr (FM > 1) { DMX_DSR(af[1], aA0, 2048); } else { DMX_DSR(af[1], aA1, 0); }
-      static_for<0, NS>([&wf0, &wf1, &af, &acc, aA0, aA1, aB1](auto ST) {
+      auto frag_step = [&wf0, &wf1, &af, &acc, aA0, aA1, aB1](auto ST) {
         constexpr int st = decltype(ST)::value;
         constexpr bool pre_a = st + 2 < NS;
         // weights of kk = 1 trickle in during kk = 0: step st (< FM) fetches wf1[j] for j in [st*FN/FM, (st+1)*FN/FM)
@@ -343,7 +347,15 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
-      });
+      };
+      constexpr int ISSUE_AT = DMX_ISSUE_AT == -2 ? NS / 2 : DMX_ISSUE_AT == -3 ? NS / 4 : DMX_ISSUE_AT < 0 ? 0 : DMX_ISSUE_AT < NS ? DMX_ISSUE_AT : NS - 1;
+      if constexpr (DMX_ISSUE_AT < 0) __builtin_amdgcn_sched_barrier(0);     // -1: right behind the prologue fragment reads (their latency covers it)
+      static_for<0, ISSUE_AT>(frag_step);
+      if constexpr (DMX_ISSUE_AT != 0) {          // the target stage is not being read: its loads may be issued under the MFMAs
+        issue(ks + NSTAGE - 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      static_for<ISSUE_AT, NS>(frag_step);
 #undef DMX_DSR
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");

@@ -162,3 +162,39 @@ def test_device_philox_noise_matches_numpy_restatement():
     assert abs(float(big.mean())) < 5e-3 and abs(float(big.std()) - 1.0) < 5e-3 and abs(float((big ** 4).mean()) - 3.0) < 0.05
     one = randn_philox((1, 8, 25, 16), [1234], 0, "cuda").cpu().reshape(-1).double().numpy()
     assert np.array_equal(one, a[1])                                   # a clip's noise does not depend on its batch
+
+
+def test_scheduler_device_noise_option():
+    """DSG with device_noise=True: the per-step noise comes from the Philox kernel keyed by the generators' seeds -- the step equals
+    the same step fed that noise explicitly, repeats exactly after set_timesteps, and advances its offset from step to step."""
+    from tests.test_gpu_step import nets as _nets_fixture, _ops, SCHED, LEN, H, W   # noqa: F401
+    from diffmusic_amd.engine import HifiGanEngine, VaeDecoderEngine
+    from tests.test_gpu_step import HIFI, VAE
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd.torch_utils import randn_philox
+    voc, vae = HifiGanEngine(HIFI), VaeDecoderEngine(VAE)
+    voc.load_state_dict(voc.synth_state_dict(seed=1))
+    vae.load_state_dict(vae.synth_state_dict(seed=2))
+    op, _ = _ops("music_inpainting")
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    y = op.forward((0.2 * torch.randn(B, LEN, generator=g)).cuda())
+    x, e = torch.randn(B, 8, H, W, generator=g).cuda(), torch.randn(B, 8, H, W, generator=g).cuda()
+    kw = dict(eta=1.0, ip_guidance_rate=0.08, measurement=y, vae=vae, vocoder=voc, original_waveform_length=LEN)
+    gens = lambda: [torch.Generator().manual_seed(100 + k) for k in range(B)]       # noqa: E731
+    s = get_scheduler("dsg")(operator=op, device_noise=True, **SCHED)
+    s.set_timesteps(200)
+    a1 = s.step(e, 501, x, generator=gens(), **kw).prev_sample.clone()
+    a2 = s.step(e, 496, x, generator=gens(), **kw).prev_sample.clone()              # second call: next Philox blocks
+    s.set_timesteps(200)
+    b1 = s.step(e, 501, x, generator=gens(), **kw).prev_sample.clone()
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    n = 8 * H * W
+    z1 = randn_philox(x.shape, [100, 101], 0, "cuda")
+    z2 = randn_philox(x.shape, [100, 101], (n + 3) // 4, "cuda")
+    ref = get_scheduler("dsg")(operator=op, **SCHED)
+    ref.set_timesteps(200)
+    assert torch.equal(ref.step(e, 501, x, sample_noise=z1, **kw).prev_sample, a1)
+    assert torch.equal(ref.step(e, 496, x, sample_noise=z2, **kw).prev_sample, a2)
+    host = ref.step(e, 501, x, generator=gens(), **kw).prev_sample
+    assert not torch.equal(host, a1)                                                # the default stays torch's generator stream
