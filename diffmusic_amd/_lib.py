@@ -48,11 +48,12 @@ class GemmDesc(C.Structure):
                 ("sCo", C.c_longlong), ("sCi", C.c_longlong),
                 ("alpha", C.c_float), ("act_slope", C.c_float), ("mask_slope", C.c_float),
                 ("flags", C.c_int),
-                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ldrb", C.c_int), ("ksplit", C.c_int)]
+                ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ldrb", C.c_int), ("ksplit", C.c_int),
+                ("XB", C.c_void_p), ("B2", C.c_void_p), ("ldxb", C.c_int), ("ldb2", C.c_int)]
 
 
-EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512
+EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV, EPI_MASKBITS, EPI_BITS2 = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
 
 _SIGS = {
     "dmx_abi_version": (C.c_int, []),

@@ -32,6 +32,7 @@ struct PairParams {
   int off0A, dA, off0B, dB;              // slab row read by tap j of a stage: off0 + j * d  (taps are affine: j*dil - pad or pad - j*dil)
   int single;
   int r_from_slab;                       // stage B's residual is stage A's input: take it from the LDS slab, not from HBM
+  int a_tape_bits_only;                  // forward: the activated intermediate leaves the kernel as sign bits only (a.B2), not as a tensor
 };
 
 template <int C>
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
       if (row < nrows && t >= 0 && t < T) sv[it] = *reinterpret_cast<const uint4*>(src + ((long long)b * T + t) * C + piece * 8);
     }
     const bool masked = !single && (P.a.flags & EPI_MASK);
+    const bool maskbits = !single && (P.a.flags & EPI_MASKBITS);
     uint4 mv[K::BITS_IT];
     if (masked) {
 #pragma unroll
@@ -149,22 +151,32 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
         if (t >= 0 && t < T) mv[it] = *reinterpret_cast<const uint4*>(P.a.X + ((long long)b * T + t) * C + piece * 8);
       }
     }
+    // sign-bit mask source (1 byte per 8 channels, the layout s_bits uses): a plain copy of PAIR_ROWS x CPR bytes
+    constexpr int BPT = K::BITS_BYTES / NT;             // bytes per thread: 4 (C = 32) or 8 (C = 64 / 128), never crossing a row
+    static_assert(BPT == 4 || BPT == 8, "bit-mask copy granularity");
+    static_assert(CPR % BPT == 0, "a thread's mask bytes must stay inside one row");
+    uint32_t mb[2] = {0u, 0u};
+    if (maskbits) {
+      const int c = tid * BPT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+      if (t >= 0 && t < T) {
+        const unsigned char* src = P.a.XB + ((long long)b * T + t) * P.a.ldxb + piece;
+        mb[0] = *reinterpret_cast<const uint32_t*>(src);
+        if (BPT == 8) mb[1] = *reinterpret_cast<const uint32_t*>(src + 4);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < K::SLAB_IT; ++it) {
       const int c = tid + it * NT, row = c / CPR, piece = c % CPR;
       if (row < K::SLAB_ROWS) *reinterpret_cast<uint4*>(slab + row * PITCH + piece * 16) = sv[it];
     }
     if (masked) {
-      auto pos2 = [](uint32_t u) -> unsigned {   // bit0: low half > 0, bit1: high half > 0   (fp16/bf16: sign clear and non-zero)
-        const unsigned lo = ((u & 0x8000u) == 0u) && ((u & 0x7fffu) != 0u);
-        const unsigned hi = ((u & 0x80000000u) == 0u) && ((u & 0x7fff0000u) != 0u);
-        return lo | (hi << 1);
-      };
 #pragma unroll
-      for (int it = 0; it < K::BITS_IT; ++it) {
-        const int c = tid + it * NT;
-        s_bits[c] = (unsigned char)(pos2(mv[it].x) | (pos2(mv[it].y) << 2) | (pos2(mv[it].z) << 4) | (pos2(mv[it].w) << 6));
-      }
+      for (int it = 0; it < K::BITS_IT; ++it) s_bits[tid + it * NT] = (unsigned char)dmx_pos8(mv[it]);
+    }
+    if (maskbits) {
+      uint32_t* d = reinterpret_cast<uint32_t*>(s_bits + tid * BPT);
+      d[0] = mb[0];
+      if (BPT == 8) d[1] = mb[1];
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
       for (int n = 0; n < FN; ++n) {
         const int ch = cg * 64 + n * 16 + lq * 4;
         float v[4] = {acc[i][n][0], acc[i][n][1], acc[i][n][2], acc[i][n][3]};
-        if (fa & EPI_MASK) {
+        if (fa & (EPI_MASK | EPI_MASKBITS)) {
           const unsigned bits = (unsigned)s_bits[row * CPR + (ch >> 3)] >> (ch & 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : mslope;
@@ -289,12 +301,18 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
       }
     }
     __syncthreads();
-    if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only, full rows
+    if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only
+      // backward only needs its SIGN (the leaky-relu' mask): with EPI_BITS2 one byte per 8 channels goes out (a.B2) and the
+      // 16-bit tensor itself is written only when a caller still wants it (a.C2 non-null and not bits-only)
+      const bool bits = (fa & EPI_BITS2) != 0, full = !P.a_tape_bits_only;
 #pragma unroll
       for (int it = 0; it < K::BITS_IT; ++it) {
         const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
-        if (row >= P.loB && row < P.loB + P.BMo && t < T)
-          *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
+        if (row >= P.loB && row < P.loB + P.BMo && t < T) {
+          const uint4 v = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
+          if (full) *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = v;
+          if (bits) P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)dmx_pos8(v);
+        }
       }
     }
   }
@@ -345,17 +363,22 @@ bool dmx_conv_pair_eligible(const GemmDesc* a, const GemmDesc& b) {
   static const bool c128 = getenv("DMX_NO_PAIR128") == nullptr;
   if (C != 32 && C != 64 && !(C == 128 && c128)) return false;
   if (T < 1) return false;
-  const int bflags = EPI_BIAS | EPI_RESID | EPI_RESID_INV | EPI_ACCUM | EPI_MASK | EPI_LRELU2 | EPI_NO_C;
+  const int bflags = EPI_BIAS | EPI_RESID | EPI_RESID_INV | EPI_ACCUM | EPI_MASK | EPI_LRELU2 | EPI_NO_C | EPI_MASKBITS | EPI_BITS2;
   if (!stage_ok(b, C, T, bflags) || !halo_of(b).ok) return false;
   if ((b.flags & EPI_LRELU2) && !(b.act_slope >= 0.f && b.act_slope <= 1.f)) return false;
   if ((b.flags & EPI_RESID_INV) && !(b.resid_inv_slope >= 1.f)) return false;
   if (b.ldc != C || ((b.flags & EPI_RESID) && b.ldr != C) || ((b.flags & EPI_MASK) && b.ldx != C) || ((b.flags & EPI_LRELU2) && b.ldc2 != C))
     return false;
+  if ((b.flags & EPI_MASKBITS) && (!b.XB || b.ldxb * 8 < C)) return false;
+  if ((b.flags & EPI_BITS2) && (!b.B2 || b.ldb2 * 8 < C)) return false;
   if (a) {
-    if (!stage_ok(*a, C, T, EPI_BIAS | EPI_LRELU2 | EPI_NO_C | EPI_MASK) || !halo_of(*a).ok) return false;
+    if (!stage_ok(*a, C, T, EPI_BIAS | EPI_LRELU2 | EPI_NO_C | EPI_MASK | EPI_MASKBITS | EPI_BITS2) || !halo_of(*a).ok) return false;
     if (a->M != b.M || a->alpha != 1.f) return false;
-    if ((a->flags & EPI_LRELU2) && (a->ldc2 != C || !a->C2)) return false;
+    if ((a->flags & EPI_LRELU2) && !(a->flags & EPI_BITS2) && (a->ldc2 != C || !a->C2)) return false;    // a tape must leave the kernel
+    if ((a->flags & EPI_LRELU2) && a->C2 && a->ldc2 != C) return false;
+    if ((a->flags & EPI_BITS2) && (!(a->flags & EPI_LRELU2) || !a->B2 || a->ldb2 * 8 < C)) return false;
     if ((a->flags & EPI_MASK) && (a->ldx != C || !a->X)) return false;
+    if ((a->flags & EPI_MASKBITS) && (!a->XB || a->ldxb * 8 < C || (a->flags & EPI_MASK))) return false;
     const Halo hb = halo_of(b);
     if (PAIR_ROWS - hb.lo - hb.hi < 128) return false;
   }
@@ -379,15 +402,25 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   P.BMo = a ? PAIR_ROWS - hb.lo - hb.hi : PAIR_ROWS;
   P.nb = cdiv(P.T, P.BMo);
   P.r_from_slab = (a && (b.flags & EPI_RESID) && b.R == a->A && b.ldr == b.N) ? 1 : 0;
+  P.a_tape_bits_only = (a && (a->flags & EPI_BITS2) && !a->C2) ? 1 : 0;
   const int nclips = b.M / P.T;
   const long long grid = (long long)nclips * P.nb;
   if (grid > 0x7fffffffLL) return DMX_ERR_SHAPE;
   const int C = b.N;
   double fl = 2.0 * b.M * (double)b.N * b.K;
   double by = 2.0 * b.M * (double)C * 2.0;                     // input + output
-  if (a) { fl += 2.0 * a->M * (double)a->N * a->K; if (a->flags & EPI_LRELU2) by += 2.0 * b.M * (double)C; if (a->flags & EPI_MASK) by += 2.0 * b.M * (double)C; }
+  const double bits_by = b.M * (double)C / 8.0;
+  if (a) {
+    fl += 2.0 * a->M * (double)a->N * a->K;
+    if ((a->flags & EPI_LRELU2) && !P.a_tape_bits_only) by += 2.0 * b.M * (double)C;
+    if (a->flags & EPI_BITS2) by += bits_by;
+    if (a->flags & EPI_MASK) by += 2.0 * b.M * (double)C;
+    if (a->flags & EPI_MASKBITS) by += bits_by;
+  }
   if ((b.flags & EPI_RESID) && !P.r_from_slab) by += 2.0 * b.M * (double)C;
   if (b.flags & EPI_MASK) by += 2.0 * b.M * (double)C;
+  if (b.flags & EPI_MASKBITS) by += bits_by;
+  if (b.flags & EPI_BITS2) by += bits_by;
   if (b.flags & EPI_ACCUM) by += 2.0 * b.M * (double)C;
   if ((b.flags & EPI_LRELU2) && !(b.flags & EPI_NO_C)) by += 2.0 * b.M * (double)C;
   const int rec = dmx_prof_open(st);

@@ -87,7 +87,10 @@ enum {
   EPI_TANH = 64,       // v = tanh(v)
   EPI_F32OUT = 128,    // C is float* instead of bf16*
   EPI_NO_C = 256,      // skip the primary output (only C2)
-  EPI_RESID_INV = 512  // R holds leaky_relu(x, 1/resid_inv_slope): the residual added is the reconstructed x
+  EPI_RESID_INV = 512, // R holds leaky_relu(x, 1/resid_inv_slope): the residual added is the reconstructed x
+  EPI_MASKBITS = 1024, // like EPI_MASK, but the mask source is a SIGN-BIT tensor XB: byte [row][n / 8], bit (n & 7) set <=> x > 0
+  EPI_BITS2 = 2048     // also write the sign bits (v > 0) of the stored value to B2 (same layout): the leaky-relu' mask of the
+                       // backward sweep at 1/16 of the bytes of the 16-bit tensor (HiFi-GAN tape)
 };
 
 struct GemmDesc {
@@ -115,6 +118,9 @@ struct GemmDesc {
   int tile_cfg;          // 0 = automatic; 1..6 force a tile configuration (tuning hook)
   int ldrb;              // row stride of rowbias in floats (0 = N); > N when it is a slice of a batched projection
   int ksplit;            // internal: > 1 = this launch is one K slice per blockIdx.z writing fp32 partials (set by the dispatcher)
+  const unsigned char* XB;   // EPI_MASKBITS source, row stride ldxb bytes (rows indexed like C; Z must be 1)
+  unsigned char* B2;         // EPI_BITS2 destination, row stride ldb2 bytes
+  int ldxb, ldb2;
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);

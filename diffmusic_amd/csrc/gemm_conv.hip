@@ -301,11 +301,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
   int cur = 0, nxt = NSTAGE - 1;
-#ifndef DMX_ISSUE_AT
-#define DMX_ISSUE_AT 0      // fragment step before which the LDS-DMA of tile ks + NSTAGE - 1 is issued (0: ahead of the fragment reads)
-#endif
   for (int ks = 0; ks < nk; ++ks) {
-    if constexpr (DMX_ISSUE_AT == 0) issue(ks + NSTAGE - 1, nxt);
     const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
     const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
     {
@@ -348,14 +344,14 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
         for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       };
-      constexpr int ISSUE_AT = DMX_ISSUE_AT == -2 ? NS / 2 : DMX_ISSUE_AT == -3 ? NS / 4 : DMX_ISSUE_AT < 0 ? 0 : DMX_ISSUE_AT < NS ? DMX_ISSUE_AT : NS - 1;
-      if constexpr (DMX_ISSUE_AT < 0) __builtin_amdgcn_sched_barrier(0);     // -1: right behind the prologue fragment reads (their latency covers it)
-      static_for<0, ISSUE_AT>(frag_step);
-      if constexpr (DMX_ISSUE_AT != 0) {          // the target stage is not being read: its loads may be issued under the MFMAs
-        issue(ks + NSTAGE - 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      static_for<ISSUE_AT, NS>(frag_step);
+      // The LDS-DMA of tile ks + NSTAGE - 1 goes out right behind the prologue fragment reads: its ~70 address instructions run
+      // under the latency of those reads instead of in front of them.  (Measured on the benchmark step: ahead of the reads
+      // 44.5 ms, here 44.15, after a quarter / half of the MFMAs 44.1 / 44.7 -- later issue leaves the loads too little time
+      // to land before the end-of-step wait once the operands come from HBM rather than from a warm L2.)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(ks + NSTAGE - 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NS>(frag_step);
 #undef DMX_DSR
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
@@ -614,7 +610,7 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
 int splitk_plan(const GemmDesc& d) {
   static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
   if (off || !g_splitk_ws || d.Z != 1 || d.tile_cfg || !glds_ok(d)) return 1;
-  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH)) return 1;
+  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2)) return 1;
   if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
   if ((d.N & 7) || (d.ldc & 3) || d.M > 8192) return 1;
   const int nk = (d.K + BK - 1) / BK;
@@ -673,6 +669,12 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   // the LDS epilogue evaluates leaky-relu as max(v, v*slope) and the inverse as min(x, x/slope)
   if ((d.flags & EPI_LRELU2) && !(d.act_slope >= 0.f && d.act_slope <= 1.f)) return DMX_ERR_SHAPE;
   if ((d.flags & EPI_RESID_INV) && !(d.resid_inv_slope >= 1.f)) return DMX_ERR_SHAPE;
+  if (d.flags & (EPI_MASKBITS | EPI_BITS2)) {
+    // sign-bit tensors are handled by the LDS-staged epilogue only: 16-bit output, 16-byte granular rows, one batch
+    if ((d.flags & EPI_F32OUT) || ((d.N | d.ldc | d.ldr | d.ldx | d.ldc2) & 7) || d.Z != 1) return DMX_ERR_SHAPE;
+    if ((d.flags & EPI_MASKBITS) && (!d.XB || d.ldxb * 8 < d.N)) return DMX_ERR_SHAPE;
+    if ((d.flags & EPI_BITS2) && (!d.B2 || d.ldb2 * 8 < d.N)) return DMX_ERR_SHAPE;
+  }
   const int ksp = splitk_plan(d);
   if (!g_prof) return ksp > 1 ? launch_splitk(d, ksp, stream) : launch_dispatch(d, stream);
   ProfRec r;
@@ -685,7 +687,9 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
     if (d.flags & EPI_ACCUM) by += mn * ((d.flags & EPI_F32OUT) ? 4.0 : 2.0);
     if (d.flags & (EPI_RESID | EPI_RESID_INV)) by += mn * 2.0;
     if (d.flags & EPI_MASK) by += mn * 2.0;
-    if (d.C2) by += mn * 2.0;
+    if (d.flags & EPI_MASKBITS) by += mn / 8.0;
+    if (d.flags & EPI_BITS2) by += mn / 8.0;
+    if (d.C2 && (d.flags & EPI_LRELU2)) by += mn * 2.0;
     r.bytes = by;
   }
   r.M = d.M; r.N = d.N; r.K = d.K; r.Z = d.Z; r.taps = d.ntaps; r.flags = d.flags;

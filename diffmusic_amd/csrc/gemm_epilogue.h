@@ -86,6 +86,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
+// sign bits of 8 packed 16-bit values: bit e set <=> element e > 0 (sign clear and non-zero; fp16 and bf16 alike)
+__device__ __forceinline__ unsigned dmx_pos8(const uint4& v) {
+  auto pos2 = [](uint32_t u) -> unsigned {
+    const unsigned lo = ((u & 0x8000u) == 0u) && ((u & 0x7fffu) != 0u);
+    const unsigned hi = ((u & 0x80000000u) == 0u) && ((u & 0x7fff0000u) != 0u);
+    return lo | (hi << 1);
+  };
+  return pos2(v.x) | (pos2(v.y) << 2) | (pos2(v.z) << 4) | (pos2(v.w) << 6);
+}
+
 // rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM); 80- and 32-row chunks both measured slower
 #ifndef DMX_EPI_IB
 #define DMX_EPI_IB 4
@@ -132,27 +142,10 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     const int n = n0 + j * 16 + lq * 4;
     bcol[j] = ((flags & EPI_BIAS) && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // Optional (-DDMX_EPI_PREFETCH, off): fetch the first tensor a chunk reads (mask source, else residual, else the accumulated
-  // C) one chunk ahead into `pre`.  Measured slower on the benchmark step (+0.6 ms with 32-row chunks, +2 ms with 64-row chunks,
-  // where the extra 32 VGPRs push the 256x256 tile into scratch): the epilogue is bound by VALU issue and LDS round trips of
-  // the two waves per SIMD, not by this latency.
-  const int first = (flags & EPI_MASK) ? 0 : ((flags & EPI_RESID) && !use_rpre) ? 1 : (flags & EPI_ACCUM) ? 2 : -1;
-  const act_t* Gfirst = first == 0 ? p.X : first == 1 ? p.R : reinterpret_cast<const act_t*>(p.C);
-  const int ldfirst = first == 0 ? p.ldx : first == 1 ? p.ldr : p.ldc;
-  const bool prefetch = ident && first >= 0;
-  uint4 pre[NIT];
-  auto issue_pre = [&](int hh) {
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int m = m0 + hh * CH + it * RPI + rr;
-      const bool ok = m < mend && col_ok;
-      const long long off = ok ? (long long)m * ldfirst + ncol : 0ll;
-      pre[it] = *reinterpret_cast<const uint4*>(Gfirst + coff + off);
-      if (!ok) pre[it] = make_uint4(0, 0, 0, 0);
-    }
-  };
-#pragma unroll
-  for (int h = 0; h < FM / IB; ++h) {
+  // (static_for, not a pragma-unrolled loop: with five 32-row chunks (FM = 10) the compiler gave up on unrolling once the body
+  //  grew, indexed the accumulators dynamically and demoted all 160 of them to scratch)
+  static_for<0, FM / IB>([&](auto H) {
+    constexpr int h = decltype(H)::value;
     // ---- output row of each tile row this lane touches in the row-major phases
     int orows[NIT];          // output row (< 2^31 rows per tensor) or -1
     if (ident) {
@@ -179,12 +172,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     }
     // row-major global -> LDS -> accumulator-layout pieces, combined into acc by `f`.  All loads of a chunk are issued back to
     // back from always-valid addresses (out-of-range rows read element 0 and are zeroed): one exposed latency per tensor.
-    auto stage_in = [&](int which, const act_t* G, int ld, auto&& f) {
-      const bool from_pre = false;
-      if (from_pre) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) *reinterpret_cast<uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16) = pre[it];
-      } else {
+    auto stage_in = [&](const act_t* G, int ld, auto&& f) {
+      {
         uint4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -206,7 +195,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         }
       DMX_LDS_SYNC();
     };
-    auto stage_out = [&](act_t* G, int ld, auto&& f) {
+    auto stage_out = [&](act_t* G, int ld, bool emit_bits, auto&& f) {
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
@@ -227,13 +216,43 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       //  keep v[] in scratch: every output byte was written twice.)
 #pragma unroll
       for (int it = 0; it < HN; ++it) {
-        if (orows[g0 + it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
+        if (orows[g0 + it] >= 0 && col_ok) {
+          if (G) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
+          // EPI_BITS2: one byte per 16-byte chunk, the leaky-relu' mask of the backward sweep (bit e <=> channel ncol + e > 0)
+          if (emit_bits) p.B2[(long long)orows[g0 + it] * p.ldb2 + (ncol >> 3)] = (unsigned char)dmx_pos8(v[it]);
+        }
       }
       }
     };
-    if (flags & EPI_MASK) {
+    if (flags & EPI_MASKBITS) {
+      // mask from the sign-bit tensor: FN * 2 bytes cover this wave's 16 * FN columns of one row; the four lanes that share a row
+      // (lq = 0..3) read the same bytes and pick their nibble -- no LDS round trip, 1/16 of the bytes of the 16-bit mask source
+      static_assert(FN == 2 || FN == 4, "sign-bit masks: wave tiles of 32 or 64 columns");
       const float sl = p.mask_slope;
-      stage_in(0, p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+      const bool span_ok = n0 + FN * 16 <= p.N;               // (a partial N tile has no valid columns in the HiFi-GAN shapes)
+      const int sh0 = 8 * (lq >> 1) + 4 * (lq & 1);             // bit position of this lane's nibble inside a 16-column pair
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const int r = ii * 16 + lr;
+        int orow;
+        if (ident) { const int m = m0 + h * CH + r; orow = m < mend ? m : -1; }
+        else orow = tab[r];
+        uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu;
+        if (orow >= 0 && span_ok) {
+          const unsigned char* src = p.XB + (long long)orow * p.ldxb + (n0 >> 3);
+          if constexpr (FN == 4) { const uint2 q = *reinterpret_cast<const uint2*>(src); q0 = q.x; q1 = q.y; }
+          else q0 = *reinterpret_cast<const uint32_t*>(src);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const unsigned nib = ((j < 2 ? q0 : q1) >> (sh0 + 16 * (j & 1)));
+          f32x4& a = acc[h * IB + ii][j];
+          a[0] *= (nib & 1u) ? 1.f : sl; a[1] *= (nib & 2u) ? 1.f : sl; a[2] *= (nib & 4u) ? 1.f : sl; a[3] *= (nib & 8u) ? 1.f : sl;
+        }
+      }
+    } else if (flags & EPI_MASK) {
+      const float sl = p.mask_slope;
+      stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
         a[0] *= x0 > 0.f ? 1.f : sl; a[1] *= x1 > 0.f ? 1.f : sl; a[2] *= x2 > 0.f ? 1.f : sl; a[3] *= x3 > 0.f ? 1.f : sl;
       });
     }
@@ -274,7 +293,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         }
     } else if (flags & EPI_RESID) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;
-      stage_in(1, p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
+      stage_in(p.R, p.ldr, [&](f32x4& a, float x0, float x1, float x2, float x3) {
         // x > 0 ? x : x * is  ==  min(x, x * is) for is >= 1 (is = 1 / leaky slope, or exactly 1 for a plain residual)
         a[0] += fminf(x0, x0 * is); a[1] += fminf(x1, x1 * is); a[2] += fminf(x2, x2 * is); a[3] += fminf(x3, x3 * is);
       });
@@ -287,26 +306,29 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] *= al; a[1] *= al; a[2] *= al; a[3] *= al; }
     }
     if (flags & EPI_ACCUM)
-      stage_in(2, reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
+      stage_in(reinterpret_cast<const act_t*>(p.C), p.ldc, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3; });
     if (flags & EPI_TANH) {
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
     }
+    const bool bits2 = (flags & EPI_BITS2) != 0;
     if (!(flags & EPI_NO_C)) {
-      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, bits2 && !(flags & EPI_LRELU2),
+                [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
       DMX_LDS_SYNC();
     }
     if (flags & EPI_LRELU2) {
       const float sl = p.act_slope;
-      stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
+      // (C2 may be null with EPI_BITS2: only the sign bits of the activated tensor are kept -- the fused pair's intermediate)
+      stage_out(p.C2, p.ldc2, bits2, [&](const f32x4& a, float (&o)[4]) {
         // leaky-relu with 0 <= slope <= 1 (checked at launch): max(v, v * slope)
         o[0] = fmaxf(a[0], a[0] * sl); o[1] = fmaxf(a[1], a[1] * sl); o[2] = fmaxf(a[2], a[2] * sl); o[3] = fmaxf(a[3], a[3] * sl);
       });
       DMX_LDS_SYNC();
     }
-  }
+  });
 #undef DMX_LDS_SYNC
 }
 

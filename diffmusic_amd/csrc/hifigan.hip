@@ -3,10 +3,12 @@
 // reference calls inside every guided step through BaseOperator.inverse_transform
 // (diffmusic/inverse_problem/operator.py:126-130; gradient path scheduling_dps.py:195-212).
 //
-// No autograd tape: the only state kept for the backward pass is the leaky-relu'd activation that
-// each convolution consumed (its sign is the leaky-relu' mask; sign(lrelu(x)) == sign(x)), and the
-// tanh output.  Weights never receive gradients, so dgrad needs no saved conv inputs.
+// No autograd tape: the only state kept for the backward pass is the SIGN of the leaky-relu'd activation
+// each convolution consumed (the leaky-relu' mask; sign(lrelu(x)) == sign(x)) -- one bit per element, written
+// by the producing epilogue (EPI_BITS2) and read by the dgrad epilogue (EPI_MASKBITS), 1/16 of the bytes of the
+// 16-bit tensor -- and the tanh output.  Weights never receive gradients, so dgrad needs no saved conv inputs.
 #include "models.h"
+#include "conv_pair.h"
 #include <cstdlib>
 
 struct HifiGan : Model {
@@ -20,8 +22,11 @@ struct HifiGan : Model {
   std::vector<int> Ts;                 // length after each stage
   act_t* act_pre = nullptr;           // lrelu(conv_pre(mel))
   std::vector<act_t*> xs_a;           // [stage] lrelu(upsampler out)
-  std::vector<act_t*> ha, xa;         // [stage][kernel][dil]
+  std::vector<act_t*> xa;             // [stage][kernel][dil] input of convs1[d] (leaky-relu'd)
   std::vector<act_t*> act_out;        // [stage] lrelu(stage output) (slope of the consumer)
+  // sign-bit tapes (1 byte per 8 channels) of the tensors above and of the intermediates lrelu(convs1 out): all backward needs
+  unsigned char* act_pre_b = nullptr;
+  std::vector<unsigned char*> xs_b, hb, xb, act_out_b;
   float* wav8 = nullptr;               // (B, Tout, 8) fp32 tanh output, channel 0 real
   bool have_tape = false;
   // The nk resblock branches of a stage are independent until their outputs are averaged: optionally (DMX_MULTI_STREAM=1) they
@@ -94,12 +99,16 @@ struct HifiGan : Model {
     B = B_; T = T_;
     Ts.assign(ns, 0);
     xs_a.assign(ns, nullptr); act_out.assign(ns, nullptr);
-    ha.assign(ns * nk * nd, nullptr); xa.assign(ns * nk * nd, nullptr);
+    xa.assign(ns * nk * nd, nullptr);
+    xs_b.assign(ns, nullptr); act_out_b.assign(ns, nullptr);
+    hb.assign(ns * nk * nd, nullptr); xb.assign(ns * nk * nd, nullptr);
     const float slope = cfg.leaky_relu_slope;
+    auto bits = [&](size_t rows, int C) { return (unsigned char*)arena.raw(rows * (size_t)(C >> 3)); };
     // conv_pre -> only the activated tensor is needed downstream
     act_pre = arena.bf((size_t)B * T * conv_pre.Cop);
+    act_pre_b = bits((size_t)B * T, conv_pre.Cop);
     {
-      Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = act_pre;
+      Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = act_pre; e.B2 = act_pre_b;
       RUN(conv_fwd_1d(conv_pre, mel, act_pre, B, T, e, st));
     }
     const act_t* cur_act = act_pre;
@@ -111,17 +120,23 @@ struct HifiGan : Model {
       Ts[s] = To;
       xs_a[s] = arena.bf(n);
       act_out[s] = arena.bf(n);
+      xs_b[s] = bits((size_t)B * To, C);
+      act_out_b[s] = bits((size_t)B * To, C);
       for (int k = 0; k < nk; ++k)
         for (int d = 0; d < nd; ++d) {
-          ha[idx(s, k, d)] = arena.bf(n);
           xa[idx(s, k, d)] = d == 0 ? xs_a[s] : arena.bf(n);
+          xb[idx(s, k, d)] = d == 0 ? xs_b[s] : bits((size_t)B * To, C);
+          hb[idx(s, k, d)] = bits((size_t)B * To, C);
         }
       const size_t mk = arena.mark();       // transients below are released per stage
+      // the activated intermediate lrelu(convs1 out) feeds convs2 and is otherwise needed only as a sign mask: one transient
+      // buffer per branch for the unfused layers (the fused pair kernel keeps it in LDS and writes the sign bits only)
+      act_t* htmp[DMX_MAX_STAGES] = {};
       // the raw residual stream x is never stored: a conv reads the leaky-relu'd tensor it needs anyway, and the residual
       // add reconstructs x = a > 0 ? a : a / slope in the epilogue (EPI_RESID_INV) -- one 16-bit tensor write less per conv2
       act_t* sum = arena.bf(n);
       {
-        Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = xs_a[s];
+        Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = xs_a[s]; e.B2 = xs_b[s];
         RUN(conv_fwd_1d(up, cur_act, xs_a[s], B, Tin, e, st));
       }
       const float next_slope = (s == ns - 1) ? 0.01f : slope;
@@ -138,24 +153,30 @@ struct HifiGan : Model {
           const int id = idx(s, k, d);
           GemmDesc da, db;
           {
-            Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = ha[id];
-            RUN(conv_fwd_1d_desc(c1[id], xa[id], ha[id], B, To, e, da));
+            Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = nullptr; e.B2 = hb[id];
+            const int rc = conv_fwd_1d_desc(c1[id], xa[id], nullptr, B, To, e, da);       // descriptor only: no launch, safe in a dry run
+            if (rc != DMX_OK) return rc;
           }
           if (d < nd - 1) {
             act_t* xn = xa[idx(s, k, d + 1)];
-            Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
-            e.act_slope = slope; e.C2 = xn;
-            RUN(conv_fwd_1d_desc(c2[id], ha[id], xn, B, To, e, db));
-            RUN(conv_pair_run(da, db, sk));
+            Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
+            e.act_slope = slope; e.C2 = xn; e.B2 = xb[idx(s, k, d + 1)];
+            const int rc = conv_fwd_1d_desc(c2[id], nullptr, xn, B, To, e, db);
+            if (rc != DMX_OK) return rc;
           } else {
             Epi e; e.flags = EPI_RESID | EPI_RESID_INV; e.R = xa[id]; e.resid_inv_slope = 1.f / slope; e.alpha = 1.f / nk;
             if (k > 0) e.flags |= EPI_ACCUM;
-            if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
-            if (mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order
-            RUN(conv_fwd_1d_desc(c2[id], ha[id], sum, B, To, e, db));
-            RUN(conv_pair_run(da, db, sk));
-            if (mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
+            if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = next_slope; e.C2 = act_out[s]; e.B2 = act_out_b[s]; }
+            const int rc = conv_fwd_1d_desc(c2[id], nullptr, sum, B, To, e, db);
+            if (rc != DMX_OK) return rc;
           }
+          if (!dmx_conv_pair_eligible(&da, db)) {       // two launches: the intermediate goes through HBM once (transient)
+            if (!htmp[k]) htmp[k] = arena.bf(n);
+            da.C2 = htmp[k]; db.A = htmp[k];
+          }
+          if (d == nd - 1 && mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order
+          RUN(conv_pair_run(da, db, sk));
+          if (d == nd - 1 && mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
         }
       }
       if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);               // join
@@ -188,7 +209,7 @@ struct HifiGan : Model {
     CHECK_WS("hifigan");
     RUN(dmx_tanh_bwd_pad8(dwav, wav8, gz, (long long)B * Tout, st));
     {
-      Epi e; e.flags = EPI_MASK; e.X = act_out[ns - 1]; e.mask_slope = 0.01f; e.alpha = 1.f / nk;
+      Epi e; e.flags = EPI_MASKBITS; e.XB = act_out_b[ns - 1]; e.mask_slope = 0.01f; e.alpha = 1.f / nk;
       RUN(conv_bwd_1d(conv_post, gz, g, B, Tout, e, st));
     }
     for (int s = ns - 1; s >= 0; --s) {
@@ -215,10 +236,10 @@ struct HifiGan : Model {
           const int id = idx(s, k, d);
           GemmDesc da, db;
           {
-            Epi e; e.flags = EPI_MASK; e.X = ha[id]; e.mask_slope = slope;
+            Epi e; e.flags = EPI_MASKBITS; e.XB = hb[id]; e.mask_slope = slope;
             RUN(conv_bwd_1d_desc(c2[id], gc, ghk[k], B, To, e, da));
           }
-          Epi e; e.flags = EPI_MASK | EPI_RESID; e.X = xa[id]; e.mask_slope = slope; e.R = gc;
+          Epi e; e.flags = EPI_MASKBITS | EPI_RESID; e.XB = xb[id]; e.mask_slope = slope; e.R = gc;
           act_t* dst;
           if (d == 0) {
             dst = gxs;
@@ -236,8 +257,8 @@ struct HifiGan : Model {
       if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);
       // through the upsampler (strided conv) and the leaky-relu that fed it
       {
-        Epi e; e.flags = EPI_MASK; e.mask_slope = slope;
-        if (s > 0) { e.X = act_out[s - 1]; e.alpha = 1.f / nk; } else { e.X = act_pre; }
+        Epi e; e.flags = EPI_MASKBITS; e.mask_slope = slope;
+        if (s > 0) { e.XB = act_out_b[s - 1]; e.alpha = 1.f / nk; } else { e.XB = act_pre_b; }
         RUN(conv_bwd_1d(ups[s], gxs, gprev, B, Tin, e, st));
       }
       g = gprev;   // (buffers of this stage stay allocated until the end of backward; sizes shrink geometrically)

@@ -75,6 +75,8 @@ struct Epi {
   act_t* C2 = nullptr;
   const float* rowbias = nullptr;
   int ldrb = 0;                 // row stride of rowbias (0 = the layer's padded Cout)
+  const unsigned char* XB = nullptr;   // EPI_MASKBITS source (sign bits, N / 8 bytes per output row)
+  unsigned char* B2 = nullptr;         // EPI_BITS2 destination
 };
 
 // registry helpers

@@ -159,9 +159,11 @@ static void init_desc(GemmDesc& d, const Epi& e) {
   d.alpha = e.alpha; d.act_slope = e.act_slope; d.mask_slope = e.mask_slope; d.resid_inv_slope = e.resid_inv_slope;
   d.flags = e.flags;
   d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias; d.ldrb = e.ldrb;
+  d.XB = e.XB; d.B2 = e.B2;
 }
 static void set_out(GemmDesc& d, void* C, int Ho, int Wo, int ldc) {
   d.C = C; d.Ho = Ho; d.Wo = Wo; d.ldc = d.ldr = d.ldx = d.ldc2 = ldc;
+  d.ldxb = d.ldb2 = ldc >> 3;
 }
 
 int conv_out_len(const ConvLayer& L, int Ti) {

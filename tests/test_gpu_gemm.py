@@ -258,3 +258,83 @@ def test_split_k_small_m_conv(B, H, W, Ci, Co):
     assert _rel(outs[1], ref) < 3e-3
     assert _rel(outs[0], ref) < 3e-3
     assert _rel(outs[1], outs[0]) < 2e-3
+
+
+def _packbits(t):
+    """(rows..., C) 16-bit tensor -> sign-bit tensor (rows..., C / 8) uint8, bit e of byte k <=> channel 8k + e > 0."""
+    b = (t.float() > 0).to(torch.uint8)
+    b = b.reshape(*t.shape[:-1], t.shape[-1] // 8, 8)
+    w = (2 ** torch.arange(8, device=t.device, dtype=torch.int32)).to(torch.uint8)
+    return (b * w).sum(-1).to(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("B,T,Cc,k,dil", [(2, 1000, 64, 3, 1), (3, 700, 32, 7, 3), (2, 1000, 128, 3, 1), (1, 2049, 128, 11, 5),
+                                          (2, 3000, 256, 3, 1), (1, 2500, 512, 7, 3)])
+def test_sign_bit_tape_forward_and_backward(B, T, Cc, k, dil):
+    """HiFi-GAN tape as sign bits: EPI_BITS2 writes (v > 0) of the stored activation, 1 byte per 8 channels (fused pair: also the
+    bits-only intermediate), and EPI_MASKBITS in the dgrad epilogues equals EPI_MASK on the 16-bit tensors bit for bit --
+    fused pair kernel (C <= 128) and generic tiles (C = 256 / 512) alike."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    slope = 0.1
+    xa = F.leaky_relu(torch.randn(B, T, Cc, generator=g), slope).to(_adt()).cuda()
+    w1 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    w2 = (torch.randn(Cc, Cc, k, generator=g) / (Cc * k) ** 0.5).to(_adt()).cuda()
+    b1 = torch.randn(Cc, generator=g).cuda() * 0.1
+    w1p = w1.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    w2p = w2.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+    # ---- forward, reference run: full 16-bit tensors
+    ha = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+    xn = torch.zeros_like(ha)
+    da = _conv_desc(L, xa, w1p, k, dil, Cc, B, T, C=ha, C2=ha, bias=b1, flags=L.EPI_BIAS | L.EPI_LRELU2 | L.EPI_NO_C, act_slope=slope)
+    db = _conv_desc(L, ha, w2p, k, 1, Cc, B, T, C=xn, C2=xn, R=xa, resid_inv_slope=1.0 / slope, act_slope=slope,
+                    flags=L.EPI_RESID | L.EPI_RESID_INV | L.EPI_LRELU2 | L.EPI_NO_C)
+    _run(L, da)
+    _run(L, db)
+    # ---- forward with the sign-bit outputs (pair kernel when it takes the shape, else two launches)
+    hb = torch.full((B, T, Cc // 8), 0xAA, dtype=torch.uint8, device="cuda")
+    xb = torch.full((B, T, Cc // 8), 0xAA, dtype=torch.uint8, device="cuda")
+    ha2, xn2 = torch.zeros_like(ha), torch.zeros_like(ha)
+    fused = Cc <= 128
+    da2 = _conv_desc(L, xa, w1p, k, dil, Cc, B, T, C=ha2, C2=(None if fused else ha2), B2=hb, ldb2=Cc // 8, bias=b1,
+                     flags=L.EPI_BIAS | L.EPI_LRELU2 | L.EPI_NO_C | L.EPI_BITS2, act_slope=slope)
+    db2 = _conv_desc(L, ha2, w2p, k, 1, Cc, B, T, C=xn2, C2=xn2, B2=xb, ldb2=Cc // 8, R=xa, resid_inv_slope=1.0 / slope, act_slope=slope,
+                     flags=L.EPI_RESID | L.EPI_RESID_INV | L.EPI_LRELU2 | L.EPI_NO_C | L.EPI_BITS2)
+    if fused:
+        da2.C2 = None
+        _pair_run(L, da2, db2)
+        assert float(ha2.float().abs().max()) == 0.0                    # bits-only: the intermediate never reached HBM
+    else:
+        _run(L, da2)
+        _run(L, db2)
+        assert torch.equal(ha2, ha)
+    assert _rel(xn2, xn) < 2e-3
+    # the bits are those of the tensor this run stored (fused and unfused differ by rounding of a few near-zero elements only)
+    assert torch.equal(xb, _packbits(xn2))
+    if not fused:
+        assert torch.equal(hb, _packbits(ha))
+    else:
+        assert float((hb != _packbits(ha)).float().mean()) < 2e-3
+    # ---- backward: EPI_MASKBITS == EPI_MASK on the 16-bit tensors
+    gc = torch.randn(B, T, Cc, generator=g).to(_adt()).cuda()
+    w1b = w1.permute(1, 2, 0).reshape(Cc, k * Cc).contiguous()
+    w2b = w2.permute(1, 2, 0).reshape(Cc, k * Cc).contiguous()
+    hbits, xbits = _packbits(ha), _packbits(xa)
+    res = {}
+    for mode in ("full", "bits"):
+        ghk = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+        dst = torch.zeros_like(ghk)
+        if mode == "full":
+            ea = _conv_desc(L, gc, w2b, k, 1, Cc, B, T, flip=True, C=ghk, X=ha, flags=L.EPI_MASK, mask_slope=slope)
+            eb = _conv_desc(L, ghk, w1b, k, dil, Cc, B, T, flip=True, C=dst, X=xa, R=gc, mask_slope=slope, flags=L.EPI_MASK | L.EPI_RESID)
+        else:
+            ea = _conv_desc(L, gc, w2b, k, 1, Cc, B, T, flip=True, C=ghk, XB=hbits, ldxb=Cc // 8, flags=L.EPI_MASKBITS, mask_slope=slope)
+            eb = _conv_desc(L, ghk, w1b, k, dil, Cc, B, T, flip=True, C=dst, XB=xbits, ldxb=Cc // 8, R=gc, mask_slope=slope,
+                            flags=L.EPI_MASKBITS | L.EPI_RESID)
+        if fused:
+            _pair_run(L, ea, eb)
+        else:
+            _run(L, ea)
+            _run(L, eb)
+        res[mode] = dst
+    assert torch.equal(res["full"], res["bits"])
