@@ -54,6 +54,7 @@ struct PairCfg {
   static constexpr int BITS_IT = PAIR_ROWS * CPR / NT;
   static constexpr int BITS_BYTES = PAIR_ROWS * CPR;
   static constexpr int LDS_BYTES = SLAB_BYTES + NS * TILE + BITS_BYTES;
+  static constexpr int MIN_WAVES = C == 32 ? 3 : 2;   // waves per SIMD the register allocation must leave room for (what the LDS footprint allows)
   static_assert(PER >= 1 && PAIR_ROWS * CPR % NT == 0, "tile / thread-count mismatch");
 };
 
@@ -81,7 +82,7 @@ __device__ __forceinline__ void pair_settle(PairFrags<2>& f) {
 }
 
 template <int C>
-__global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairParams P) {
+__global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pair_kernel(const PairParams P) {
   using K = PairCfg<C>;
   constexpr int PITCH = K::PITCH, CPR = K::CPR, FN = K::FN, NS = K::NS, PER = K::PER, TILE = K::TILE, NT = K::NT, NW = K::NW, WN = K::WN;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -142,15 +143,6 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
     }
     const bool masked = !single && (P.a.flags & EPI_MASK);
     const bool maskbits = !single && (P.a.flags & EPI_MASKBITS);
-    uint4 mv[K::BITS_IT];
-    if (masked) {
-#pragma unroll
-      for (int it = 0; it < K::BITS_IT; ++it) {
-        const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
-        mv[it] = make_uint4(0, 0, 0, 0);
-        if (t >= 0 && t < T) mv[it] = *reinterpret_cast<const uint4*>(P.a.X + ((long long)b * T + t) * C + piece * 8);
-      }
-    }
     // sign-bit mask source (1 byte per 8 channels, the layout s_bits uses): a plain copy of PAIR_ROWS x CPR bytes
     constexpr int BPT = K::BITS_BYTES / NT;             // bytes per thread: 4 (C = 32) or 8 (C = 64 / 128), never crossing a row
     static_assert(BPT == 4 || BPT == 8, "bit-mask copy granularity");
@@ -169,9 +161,14 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
       const int c = tid + it * NT, row = c / CPR, piece = c % CPR;
       if (row < K::SLAB_ROWS) *reinterpret_cast<uint4*>(slab + row * PITCH + piece * 16) = sv[it];
     }
-    if (masked) {
-#pragma unroll
-      for (int it = 0; it < K::BITS_IT; ++it) s_bits[tid + it * NT] = (unsigned char)dmx_pos8(mv[it]);
+    if (masked) {           // 16-bit mask source (generic callers; the HiFi-GAN executor passes sign bits): reduced to bits on the fly,
+#pragma unroll 1            // one load at a time -- holding all of them next to the slab registers cost the C = 64 instance a wave per SIMD
+      for (int it = 0; it < K::BITS_IT; ++it) {
+        const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+        uint4 m = make_uint4(0, 0, 0, 0);
+        if (t >= 0 && t < T) m = *reinterpret_cast<const uint4*>(P.a.X + ((long long)b * T + t) * C + piece * 8);
+        s_bits[c] = (unsigned char)dmx_pos8(m);
+      }
     }
     if (maskbits) {
       uint32_t* d = reinterpret_cast<uint32_t*>(s_bits + tid * BPT);
@@ -326,8 +323,8 @@ __global__ __launch_bounds__(PairCfg<C>::NT) void conv_pair_kernel(const PairPar
     static_assert(EPI_WAVE_BYTES * NW <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
     const int mbase = b * T + t0;
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
-    gemm_epilogue_lds_impl<4, FN>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
-                                  !single && P.r_from_slab != 0);
+    gemm_epilogue_lds_impl<4, FN, true>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
+                                        !single && P.r_from_slab != 0);
   }
 }
 

@@ -20,7 +20,7 @@ namespace {
 constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
 
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BITS>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, BITS>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
 }
 
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 // range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
 constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
 __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -367,7 +367,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, BITS>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
 }
 
@@ -378,44 +378,54 @@ __device__ __forceinline__ int xcd_remap(int bid) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x);
-  glds_tile<BM, BN, WM, WN, NSTAGE>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
+  glds_tile<BM, BN, WM, WN, NSTAGE, BITS>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE>
-int launch_glds(const GemmDesc& d, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
+int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int SMEM = NSTAGE * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, BITS>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE>), grid, dim3(NT), SMEM, stream, d);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, BITS>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
+// the sign-bit tape epilogue (HiFi-GAN layers) is a separate instantiation of every tile
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_glds(const GemmDesc& d, hipStream_t stream) {
+  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_glds_t<BM, BN, WM, WN, NSTAGE, true>(d, stream)
+                                                : launch_glds_t<BM, BN, WM, WN, NSTAGE, false>(d, stream);
+}
 
-template <int BM, int BN, int WM, int WN>
-int launch_cfg(const GemmDesc& d, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, bool BITS>
+int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, BITS>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(NT), SMEM, stream, d);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BITS>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmDesc& d, hipStream_t stream) {
+  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_cfg_t<BM, BN, WM, WN, true>(d, stream) : launch_cfg_t<BM, BN, WM, WN, false>(d, stream);
 }
 
 }  // namespace

@@ -86,14 +86,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc& p, f32x4 (&acc)[FM
   }
 }
 
-// sign bits of 8 packed 16-bit values: bit e set <=> element e > 0 (sign clear and non-zero; fp16 and bf16 alike)
+// sign bits of 8 packed 16-bit values: bit e set <=> element e > 0 (sign clear and non-zero; fp16 and bf16 alike).
+// Branch-free on the packed words (the epilogue is VALU-bound): a half is positive iff its magnitude is >= 1 ulp -- adding 0x7fff to
+// the 15 magnitude bits carries into bit 15 exactly then, and never across halves -- and its own sign bit is clear.
 __device__ __forceinline__ unsigned dmx_pos8(const uint4& v) {
-  auto pos2 = [](uint32_t u) -> unsigned {
-    const unsigned lo = ((u & 0x8000u) == 0u) && ((u & 0x7fffu) != 0u);
-    const unsigned hi = ((u & 0x80000000u) == 0u) && ((u & 0x7fff0000u) != 0u);
-    return lo | (hi << 1);
-  };
-  return pos2(v.x) | (pos2(v.y) << 2) | (pos2(v.z) << 4) | (pos2(v.w) << 6);
+  auto pos = [](uint32_t u) -> uint32_t { return (((u & 0x7fff7fffu) + 0x7fff7fffu) & ~u) & 0x80008000u; };   // flags at bits 15 and 31
+  const uint32_t w = (pos(v.x) >> 15) | (pos(v.y) >> 13) | (pos(v.z) >> 11) | (pos(v.w) >> 9);               // low halves: bits 0,2,4,6; high: 16,18,20,22
+  return (w & 0x55u) | ((w >> 15) & 0xaau);
 }
 
 // rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM); 80- and 32-row chunks both measured slower
@@ -110,7 +109,10 @@ struct EpiChunk { static constexpr int IB = (FM % DMX_EPI_IB == 0) ? DMX_EPI_IB 
 // source X, residual R, previous C, outputs C and C2) moves between HBM and a wave-private LDS tile in full
 // row segments (16 B per lane, TN*2-byte contiguous runs = whole cache lines) and is exchanged with the
 // accumulator layout through LDS.  Rows are handled in chunks of CH <= 64 to fit 8 waves in the stage buffers.
-template <int FM, int FN>
+// BITS: instantiate the sign-bit tape paths (EPI_MASKBITS / EPI_BITS2).  They live in SEPARATE kernel instantiations (the launcher
+// picks by flag): merely having them in the common epilogue cost every other layer ~5 % (measured on the VAE), executed or not,
+// and two copies inside one kernel pushed the 256x256 tile into scratch.
+template <int FM, int FN, bool BITS>
 __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
                                                        long long coff, int HqWq, char* wl, int mlimit,
                                                        const uint2 (&rpre)[FM * FN], const bool use_rpre) {
@@ -195,7 +197,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         }
       DMX_LDS_SYNC();
     };
-    auto stage_out = [&](act_t* G, int ld, bool emit_bits, auto&& f) {
+    auto stage_out = [&](act_t* G, int ld, auto&& f) {
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
@@ -216,20 +218,25 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       //  keep v[] in scratch: every output byte was written twice.)
 #pragma unroll
       for (int it = 0; it < HN; ++it) {
-        if (orows[g0 + it] >= 0 && col_ok) {
-          if (G) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
-          // EPI_BITS2: one byte per 16-byte chunk, the leaky-relu' mask of the backward sweep (bit e <=> channel ncol + e > 0)
-          if (emit_bits) p.B2[(long long)orows[g0 + it] * p.ldb2 + (ncol >> 3)] = (unsigned char)dmx_pos8(v[it]);
-        }
+        if (orows[g0 + it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
       }
       }
     };
-    if (flags & EPI_MASKBITS) {
+    // EPI_BITS2: a separate sweep over the packed tile stage_out left in LDS (kept out of the store loop above: the common
+    // path must not pay for it) -- one byte per 16-byte chunk, bit e <=> channel ncol + e > 0, the backward sweep's leaky-relu' mask
+    auto emit_bits = [&]() {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const uint4 v = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
+        if (orows[it] >= 0 && col_ok) p.B2[(long long)orows[it] * p.ldb2 + (ncol >> 3)] = (unsigned char)dmx_pos8(v);
+      }
+    };
+    if (BITS && (flags & EPI_MASKBITS)) {
       // mask from the sign-bit tensor: FN * 2 bytes cover this wave's 16 * FN columns of one row; the four lanes that share a row
       // (lq = 0..3) read the same bytes and pick their nibble -- no LDS round trip, 1/16 of the bytes of the 16-bit mask source
       static_assert(FN == 2 || FN == 4, "sign-bit masks: wave tiles of 32 or 64 columns");
       const float sl = p.mask_slope;
-      const bool span_ok = n0 + FN * 16 <= p.N;               // (a partial N tile has no valid columns in the HiFi-GAN shapes)
+      const bool span_ok = n0 + FN * 16 <= p.N;
       const int sh0 = 8 * (lq >> 1) + 4 * (lq & 1);             // bit position of this lane's nibble inside a 16-column pair
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii) {
@@ -238,10 +245,19 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         if (ident) { const int m = m0 + h * CH + r; orow = m < mend ? m : -1; }
         else orow = tab[r];
         uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu;
-        if (orow >= 0 && span_ok) {
+        if (orow >= 0) {
           const unsigned char* src = p.XB + (long long)orow * p.ldxb + (n0 >> 3);
-          if constexpr (FN == 4) { const uint2 q = *reinterpret_cast<const uint2*>(src); q0 = q.x; q1 = q.y; }
-          else q0 = *reinterpret_cast<const uint32_t*>(src);
+          if (span_ok) {
+            if constexpr (FN == 4) { const uint2 q = *reinterpret_cast<const uint2*>(src); q0 = q.x; q1 = q.y; }
+            else q0 = *reinterpret_cast<const uint32_t*>(src);
+          } else {                                              // N tail (narrow layers: N = 8 / 16 inside a 32-column wave tile)
+            q0 = q1 = 0u;
+#pragma unroll 1                 // rare path: keep it rolled (unrolled, its byte loads were hoisted and cost ~50 VGPRs everywhere)
+            for (int k = 0; k < FN * 2; ++k) {
+              const uint32_t by = n0 + k * 8 < p.N ? (uint32_t)src[k] : 0xffu;
+              if (k < 4) q0 |= by << (8 * k); else q1 |= by << (8 * (k - 4));
+            }
+          }
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -315,28 +331,28 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     }
     const bool bits2 = (flags & EPI_BITS2) != 0;
     if (!(flags & EPI_NO_C)) {
-      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, bits2 && !(flags & EPI_LRELU2),
-                [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+      stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
+      if constexpr (BITS) { if (bits2 && !(flags & EPI_LRELU2)) emit_bits(); }
       DMX_LDS_SYNC();
     }
     if (flags & EPI_LRELU2) {
       const float sl = p.act_slope;
-      // (C2 may be null with EPI_BITS2: only the sign bits of the activated tensor are kept -- the fused pair's intermediate)
-      stage_out(p.C2, p.ldc2, bits2, [&](const f32x4& a, float (&o)[4]) {
+      stage_out(p.C2, p.ldc2, [&](const f32x4& a, float (&o)[4]) {
         // leaky-relu with 0 <= slope <= 1 (checked at launch): max(v, v * slope)
         o[0] = fmaxf(a[0], a[0] * sl); o[1] = fmaxf(a[1], a[1] * sl); o[2] = fmaxf(a[2], a[2] * sl); o[3] = fmaxf(a[3], a[3] * sl);
       });
+      if constexpr (BITS) { if (bits2) emit_bits(); }
       DMX_LDS_SYNC();
     }
   });
 #undef DMX_LDS_SYNC
 }
 
-template <int FM, int FN>
+template <int FM, int FN, bool BITS>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
                                                   long long coff, int HqWq, char* wl, int mlimit = 0x7fffffff) {
   const uint2 none[FM * FN] = {};
-  gemm_epilogue_lds_impl<FM, FN>(p, acc, m0, n0, lane, coff, HqWq, wl, mlimit, none, false);
+  gemm_epilogue_lds_impl<FM, FN, BITS>(p, acc, m0, n0, lane, coff, HqWq, wl, mlimit, none, false);
 }
 
 }  // namespace

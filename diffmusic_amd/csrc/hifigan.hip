@@ -3,10 +3,13 @@
 // reference calls inside every guided step through BaseOperator.inverse_transform
 // (diffmusic/inverse_problem/operator.py:126-130; gradient path scheduling_dps.py:195-212).
 //
-// No autograd tape: the only state kept for the backward pass is the SIGN of the leaky-relu'd activation
-// each convolution consumed (the leaky-relu' mask; sign(lrelu(x)) == sign(x)) -- one bit per element, written
-// by the producing epilogue (EPI_BITS2) and read by the dgrad epilogue (EPI_MASKBITS), 1/16 of the bytes of the
-// 16-bit tensor -- and the tanh output.  Weights never receive gradients, so dgrad needs no saved conv inputs.
+// No autograd tape: the only state kept for the backward pass is the leaky-relu'd activation that each
+// convolution consumed (its sign is the leaky-relu' mask; sign(lrelu(x)) == sign(x)) and the tanh output;
+// weights never receive gradients, so dgrad needs no saved conv inputs.  In the narrow stages (C <= 128), whose
+// resblock steps run in the fused pair kernel and are HBM-bound, the mask travels as SIGN BITS instead (1 byte
+// per 8 channels, EPI_BITS2 -> EPI_MASKBITS): the intermediate lrelu(convs1 out) never leaves LDS as a tensor
+// and the dgrad pair reads 2/16 instead of 2 mask tensors.  The wide stages (C = 256 / 512, generic tiles whose
+// epilogues are VALU-bound) keep 16-bit masks: extracting the bits there cost as much as reading them saved.
 #include "models.h"
 #include "conv_pair.h"
 #include <cstdlib>
@@ -22,11 +25,11 @@ struct HifiGan : Model {
   std::vector<int> Ts;                 // length after each stage
   act_t* act_pre = nullptr;           // lrelu(conv_pre(mel))
   std::vector<act_t*> xs_a;           // [stage] lrelu(upsampler out)
-  std::vector<act_t*> xa;             // [stage][kernel][dil] input of convs1[d] (leaky-relu'd)
+  std::vector<act_t*> ha, xa;         // [stage][kernel][dil] lrelu(convs1 out) (unfused steps only) / input of convs1[d]
   std::vector<act_t*> act_out;        // [stage] lrelu(stage output) (slope of the consumer)
-  // sign-bit tapes (1 byte per 8 channels) of the tensors above and of the intermediates lrelu(convs1 out): all backward needs
-  unsigned char* act_pre_b = nullptr;
-  std::vector<unsigned char*> xs_b, hb, xb, act_out_b;
+  // fused steps: sign-bit tapes (1 byte per 8 channels) of xa and of the intermediate lrelu(convs1 out)
+  std::vector<unsigned char*> hb, xb;
+  std::vector<char> fused;            // [stage][kernel][dil] this resblock step runs in the fused pair kernel
   float* wav8 = nullptr;               // (B, Tout, 8) fp32 tanh output, channel 0 real
   bool have_tape = false;
   // The nk resblock branches of a stage are independent until their outputs are averaged: optionally (DMX_MULTI_STREAM=1) they
@@ -85,6 +88,20 @@ struct HifiGan : Model {
     return rc;
   }
 
+  // does resblock step `id` (length To per clip) go to the fused pair kernel?  Decided from the shapes alone, before any buffer
+  // exists (it selects the tape format: sign bits vs 16-bit tensors), with the flag sets the forward pass will use.
+  bool step_is_fused(int id, int To) const {
+    GemmDesc da, db;
+    act_t* dummy = reinterpret_cast<act_t*>(size_t(256));
+    unsigned char* dummyb = reinterpret_cast<unsigned char*>(size_t(256));
+    Epi ea; ea.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; ea.act_slope = cfg.leaky_relu_slope; ea.B2 = dummyb;
+    if (conv_fwd_1d_desc(c1[id], dummy, nullptr, B, To, ea, da) != DMX_OK) return false;
+    Epi eb; eb.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C | EPI_ACCUM; eb.R = dummy; eb.C2 = dummy;
+    eb.resid_inv_slope = 1.f / cfg.leaky_relu_slope; eb.act_slope = cfg.leaky_relu_slope;
+    if (conv_fwd_1d_desc(c2[id], nullptr, dummy, B, To, eb, db) != DMX_OK) return false;
+    return dmx_conv_pair_eligible(&da, db);
+  }
+
   int out_len(int T_) const {
     int t = T_;
     for (int i = 0; i < ns; ++i) t = conv_out_len(ups[i], t);
@@ -99,16 +116,15 @@ struct HifiGan : Model {
     B = B_; T = T_;
     Ts.assign(ns, 0);
     xs_a.assign(ns, nullptr); act_out.assign(ns, nullptr);
-    xa.assign(ns * nk * nd, nullptr);
-    xs_b.assign(ns, nullptr); act_out_b.assign(ns, nullptr);
+    ha.assign(ns * nk * nd, nullptr); xa.assign(ns * nk * nd, nullptr);
     hb.assign(ns * nk * nd, nullptr); xb.assign(ns * nk * nd, nullptr);
+    fused.assign(ns * nk * nd, 0);
     const float slope = cfg.leaky_relu_slope;
     auto bits = [&](size_t rows, int C) { return (unsigned char*)arena.raw(rows * (size_t)(C >> 3)); };
     // conv_pre -> only the activated tensor is needed downstream
     act_pre = arena.bf((size_t)B * T * conv_pre.Cop);
-    act_pre_b = bits((size_t)B * T, conv_pre.Cop);
     {
-      Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = act_pre; e.B2 = act_pre_b;
+      Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = act_pre;
       RUN(conv_fwd_1d(conv_pre, mel, act_pre, B, T, e, st));
     }
     const act_t* cur_act = act_pre;
@@ -120,23 +136,27 @@ struct HifiGan : Model {
       Ts[s] = To;
       xs_a[s] = arena.bf(n);
       act_out[s] = arena.bf(n);
-      xs_b[s] = bits((size_t)B * To, C);
-      act_out_b[s] = bits((size_t)B * To, C);
+      unsigned char* xs_b = nullptr;        // sign bits of xs_a, wanted when a first resblock step of the stage is fused
       for (int k = 0; k < nk; ++k)
         for (int d = 0; d < nd; ++d) {
-          xa[idx(s, k, d)] = d == 0 ? xs_a[s] : arena.bf(n);
-          xb[idx(s, k, d)] = d == 0 ? xs_b[s] : bits((size_t)B * To, C);
-          hb[idx(s, k, d)] = bits((size_t)B * To, C);
+          const int id = idx(s, k, d);
+          fused[id] = step_is_fused(id, To) ? 1 : 0;
+          xa[id] = d == 0 ? xs_a[s] : arena.bf(n);
+          if (fused[id]) {
+            hb[id] = bits((size_t)B * To, C);
+            if (d == 0) { if (!xs_b) xs_b = bits((size_t)B * To, C); xb[id] = xs_b; }
+            else xb[id] = bits((size_t)B * To, C);
+          } else {
+            ha[id] = arena.bf(n);
+          }
         }
       const size_t mk = arena.mark();       // transients below are released per stage
-      // the activated intermediate lrelu(convs1 out) feeds convs2 and is otherwise needed only as a sign mask: one transient
-      // buffer per branch for the unfused layers (the fused pair kernel keeps it in LDS and writes the sign bits only)
-      act_t* htmp[DMX_MAX_STAGES] = {};
       // the raw residual stream x is never stored: a conv reads the leaky-relu'd tensor it needs anyway, and the residual
       // add reconstructs x = a > 0 ? a : a / slope in the epilogue (EPI_RESID_INV) -- one 16-bit tensor write less per conv2
       act_t* sum = arena.bf(n);
       {
-        Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = xs_a[s]; e.B2 = xs_b[s];
+        Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope; e.C2 = xs_a[s];
+        if (xs_b) { e.flags |= EPI_BITS2; e.B2 = xs_b; }
         RUN(conv_fwd_1d(up, cur_act, xs_a[s], B, Tin, e, st));
       }
       const float next_slope = (s == ns - 1) ? 0.01f : slope;
@@ -151,28 +171,30 @@ struct HifiGan : Model {
         hipStream_t sk = (mt && k > 0) ? bstream[k] : st;
         for (int d = 0; d < nd; ++d) {
           const int id = idx(s, k, d);
+          const bool fz = fused[id] != 0;
           GemmDesc da, db;
           {
-            Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.C2 = nullptr; e.B2 = hb[id];
-            const int rc = conv_fwd_1d_desc(c1[id], xa[id], nullptr, B, To, e, da);       // descriptor only: no launch, safe in a dry run
-            if (rc != DMX_OK) return rc;
+            // fused: the activated intermediate stays in LDS, only its sign bits are written; unfused: it is a tape tensor
+            Epi e; e.flags = EPI_LRELU2 | EPI_NO_C; e.act_slope = slope;
+            if (fz) { e.flags |= EPI_BITS2; e.B2 = hb[id]; } else e.C2 = ha[id];
+            RUN(conv_fwd_1d_desc(c1[id], xa[id], ha[id], B, To, e, da));
           }
           if (d < nd - 1) {
-            act_t* xn = xa[idx(s, k, d + 1)];
-            Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
-            e.act_slope = slope; e.C2 = xn; e.B2 = xb[idx(s, k, d + 1)];
-            const int rc = conv_fwd_1d_desc(c2[id], nullptr, xn, B, To, e, db);
-            if (rc != DMX_OK) return rc;
+            const int idn = idx(s, k, d + 1);
+            act_t* xn = xa[idn];
+            Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
+            e.act_slope = slope; e.C2 = xn;
+            if (fused[idn]) { e.flags |= EPI_BITS2; e.B2 = xb[idn]; }
+            RUN(conv_fwd_1d_desc(c2[id], ha[id], xn, B, To, e, db));
           } else {
             Epi e; e.flags = EPI_RESID | EPI_RESID_INV; e.R = xa[id]; e.resid_inv_slope = 1.f / slope; e.alpha = 1.f / nk;
             if (k > 0) e.flags |= EPI_ACCUM;
-            if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = next_slope; e.C2 = act_out[s]; e.B2 = act_out_b[s]; }
-            const int rc = conv_fwd_1d_desc(c2[id], nullptr, sum, B, To, e, db);
-            if (rc != DMX_OK) return rc;
+            if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
+            RUN(conv_fwd_1d_desc(c2[id], ha[id], sum, B, To, e, db));
           }
-          if (!dmx_conv_pair_eligible(&da, db)) {       // two launches: the intermediate goes through HBM once (transient)
-            if (!htmp[k]) htmp[k] = arena.bf(n);
-            da.C2 = htmp[k]; db.A = htmp[k];
+          if (!dry && fz && !dmx_conv_pair_eligible(&da, db)) {       // the tape format was chosen for the fused kernel: never fall back silently
+            dmx_set_error("hifigan: resblock step %d was planned as fused but the pair kernel refuses it", id);
+            return DMX_ERR_STATE;
           }
           if (d == nd - 1 && mt && fin_prev) (void)hipStreamWaitEvent(sk, fin_prev, 0);      // the averaged sum is accumulated in branch order
           RUN(conv_pair_run(da, db, sk));
@@ -209,7 +231,7 @@ struct HifiGan : Model {
     CHECK_WS("hifigan");
     RUN(dmx_tanh_bwd_pad8(dwav, wav8, gz, (long long)B * Tout, st));
     {
-      Epi e; e.flags = EPI_MASKBITS; e.XB = act_out_b[ns - 1]; e.mask_slope = 0.01f; e.alpha = 1.f / nk;
+      Epi e; e.flags = EPI_MASK; e.X = act_out[ns - 1]; e.mask_slope = 0.01f; e.alpha = 1.f / nk;
       RUN(conv_bwd_1d(conv_post, gz, g, B, Tout, e, st));
     }
     for (int s = ns - 1; s >= 0; --s) {
@@ -236,10 +258,12 @@ struct HifiGan : Model {
           const int id = idx(s, k, d);
           GemmDesc da, db;
           {
-            Epi e; e.flags = EPI_MASKBITS; e.XB = hb[id]; e.mask_slope = slope;
+            Epi e; e.mask_slope = slope;
+            if (fused[id]) { e.flags = EPI_MASKBITS; e.XB = hb[id]; } else { e.flags = EPI_MASK; e.X = ha[id]; }
             RUN(conv_bwd_1d_desc(c2[id], gc, ghk[k], B, To, e, da));
           }
-          Epi e; e.flags = EPI_MASKBITS | EPI_RESID; e.XB = xb[id]; e.mask_slope = slope; e.R = gc;
+          Epi e; e.flags = EPI_RESID; e.mask_slope = slope; e.R = gc;
+          if (fused[id]) { e.flags |= EPI_MASKBITS; e.XB = xb[id]; } else { e.flags |= EPI_MASK; e.X = xa[id]; }
           act_t* dst;
           if (d == 0) {
             dst = gxs;
@@ -257,8 +281,8 @@ struct HifiGan : Model {
       if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);
       // through the upsampler (strided conv) and the leaky-relu that fed it
       {
-        Epi e; e.flags = EPI_MASKBITS; e.mask_slope = slope;
-        if (s > 0) { e.XB = act_out_b[s - 1]; e.alpha = 1.f / nk; } else { e.XB = act_pre_b; }
+        Epi e; e.flags = EPI_MASK; e.mask_slope = slope;
+        if (s > 0) { e.X = act_out[s - 1]; e.alpha = 1.f / nk; } else { e.X = act_pre; }
         RUN(conv_bwd_1d(ups[s], gxs, gprev, B, Tin, e, st));
       }
       g = gprev;   // (buffers of this stage stay allocated until the end of backward; sizes shrink geometrically)
