@@ -239,49 +239,50 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int ks0 = sp * ks_per, ks1 = ks0 + ks_per < nk_all ? ks0 + ks_per : nk_all;
   // tap-inner walk without divisions: (tap, channel group) of the NEXT step to be issued; issue() is called with consecutive steps
   int i_cg = ks0 / p.ntaps, i_tp = ks0 - i_cg * p.ntaps;
-  auto issue = [&](int ksl, int stage) {
-    char* sbase = smem + stage * STAGE;
+  // One K step's LDS-DMA is split in two parts so that its PER instructions can be spread over the fragment steps (an LDS-DMA
+  // issued back to back with seven others and a burst of ds_reads costs the wave 100-185 cycles, one slipped between MFMA groups
+  // 25-60; MI355X_MICROARCH.md): issue_begin() computes what depends on the K step only, issue_one<I>() sends instruction I.
+  bool q_kval = false;          // this lane's chunk of the step exists (K tail, split-K range, partial last channel group)
+  int q_dy = 0, q_dx = 0;
+  unsigned q_adel = 0, q_wdel = 0;   // byte deltas added to the per-row A offsets / weight-row offsets
+  char* q_base = nullptr;
+  auto issue_begin = [&](int ksl, int stage) {
+    q_base = smem + stage * STAGE;
     if (tap_inner) {
       // everything that depends on the K step is wave-uniform here: one readlane for the tap, one scalar byte delta for all rows
       const int tp = __builtin_amdgcn_readfirstlane(i_tp), cgi = __builtin_amdgcn_readfirstlane(i_cg);
-      const bool kval = cgi < cgroups && ksl + ks0 < ks1 && cgi * 8 + cc < cpt;     // (lane term: partial last group when Ci % 64 != 0)
+      q_kval = cgi < cgroups && ksl + ks0 < ks1 && cgi * 8 + cc < cpt;     // (lane term: partial last group when Ci % 64 != 0)
       const int tv = __builtin_amdgcn_readlane(tapreg, tp);
-      const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
-      const unsigned sdel = (unsigned)((dy * p.Wi + dx) * (int)lda2) + ((unsigned)cgi << 7);       // tap shift + 64-channel group, bytes
-      const unsigned skc = (unsigned)(tp * cpt + cgi * 8 + cc) << 4;                                  // weight-row byte offset of this chunk
-#pragma unroll
-      for (int i = 0; i < A_ISS; ++i) {
-        const bool ok = kval && (unsigned)(a_iy[i] + dy) < (unsigned)p.Hi && (unsigned)(a_ix[i] + dx) < (unsigned)p.Wi;
-        const unsigned voff = ok ? a_lin[i] + sdel : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < B_ISS; ++i) {
-        const unsigned voff = (kval && w_off[i] != OOB) ? w_off[i] + skc : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
-      }
+      q_dy = (int)(signed char)(tv & 0xff); q_dx = (int)(signed char)((tv >> 8) & 0xff);
+      q_adel = (unsigned)((q_dy * p.Wi + q_dx) * (int)lda2) + ((unsigned)cgi << 7);       // tap shift + 64-channel group, bytes
+      q_wdel = (unsigned)(tp * cpt + cgi * 8 + cc) << 4;                                      // weight-row byte offset of this chunk
       if (++i_tp == p.ntaps) { i_tp = 0; ++i_cg; }
-      return;
+    } else {
+      const int ks = ksl + ks0;
+      const int kc = ks * 8 + cc;
+      const int tap = kc / cpt;
+      q_kval = kc < kchunks && ks < ks1;
+      const int tv = __builtin_amdgcn_ds_bpermute((tap & (DMX_MAX_TAPS - 1)) << 2, tapreg);
+      q_dy = (int)(signed char)(tv & 0xff); q_dx = (int)(signed char)((tv >> 8) & 0xff);
+      q_adel = (unsigned)((q_dy * p.Wi + q_dx) * (int)lda2) + ((unsigned)(kc - tap * cpt) << 4) - ((unsigned)cc << 4);   // a_lin already holds cc * 16
+      q_wdel = (unsigned)kc << 4;
     }
-    const int ks = ksl + ks0;
-    const int kc = ks * 8 + cc;
-    const int tap = kc / cpt;
-    const unsigned cin2 = (unsigned)(kc - tap * cpt) << 4;      // byte offset of the chunk inside the pixel
-    const bool kval = kc < kchunks && ks < ks1;
-    const int tv = __builtin_amdgcn_ds_bpermute((tap & (DMX_MAX_TAPS - 1)) << 2, tapreg);
-    const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
-#pragma unroll
-    for (int i = 0; i < A_ISS; ++i) {
-      const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
-      const bool ok = kval && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-      const unsigned voff = ok ? a_boff[i] + (unsigned)(iy * p.Wi + ix) * lda2 + cin2 : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(sbase + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+  };
+  auto issue_one = [&](auto I) {
+    constexpr int i = decltype(I)::value;
+    if constexpr (i < A_ISS) {
+      const bool ok = q_kval && (unsigned)(a_iy[i] + q_dy) < (unsigned)p.Hi && (unsigned)(a_ix[i] + q_dx) < (unsigned)p.Wi;
+      const unsigned voff = ok ? a_lin[i] + q_adel : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(q_base + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
+    } else {
+      constexpr int j = i - A_ISS;
+      const unsigned voff = (q_kval && w_off[j] != OOB) ? w_off[j] + q_wdel : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(q_base + A_BYTES + (j * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < B_ISS; ++i) {
-      const unsigned voff = (kval && w_off[i] != OOB) ? w_off[i] + ((unsigned)kc << 4) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(sbase + A_BYTES + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
-    }
+  };
+  auto issue = [&](int ksl, int stage) {          // whole step at once (ring prologue)
+    issue_begin(ksl, stage);
+    static_for<0, PER>(issue_one);
   };
 
   const int wm = wave / WN, wn = wave - wm * WN;
@@ -344,14 +345,20 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
         for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
       };
-      // The LDS-DMA of tile ks + NSTAGE - 1 goes out right behind the prologue fragment reads: its ~70 address instructions run
-      // under the latency of those reads instead of in front of them.  (Measured on the benchmark step: ahead of the reads
-      // 44.5 ms, here 44.15, after a quarter / half of the MFMAs 44.1 / 44.7 -- later issue leaves the loads too little time
-      // to land before the end-of-step wait once the operands come from HBM rather than from a warm L2.)
+      // The address arithmetic of tile ks + NSTAGE - 1 runs right behind the prologue fragment reads (under their latency).
       __builtin_amdgcn_sched_barrier(0);
-      issue(ks + NSTAGE - 1, nxt);
+      issue_begin(ks + NSTAGE - 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
-      static_for<0, NS>(frag_step);
+      // the PER LDS-DMA instructions of the step are slipped in behind the MFMA groups of the first SPREAD fragment steps
+      constexpr int SPREAD = NS / 2 > 0 ? NS / 2 : 1;
+      static_for<0, NS>([&](auto ST) {
+        constexpr int st = decltype(ST)::value;
+        frag_step(ST);
+        if constexpr (st < SPREAD) {
+          static_for<st * PER / SPREAD, (st + 1) * PER / SPREAD>(issue_one);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
 #undef DMX_DSR
     }
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
