@@ -217,20 +217,23 @@ __global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pa
       DMX_PAIR_DSR(f.w[1][n], wa1, n * 2048);
     });
   };
-  auto mfma_block = [&](const Frags& f) {
+  auto mfma_half = [&](const Frags& f, int ks) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int n = 0; n < FN; ++n) acc[i][n] = DMX_MFMA16(f.w[ks][n], f.x[ks][i], acc[i][n]);
+      for (int n = 0; n < FN; ++n) acc[i][n] = DMX_MFMA16(f.w[ks][n], f.x[ks][i], acc[i][n]);
   };
-  // one K step: the next step's fragments and the weight tile three steps ahead are in flight under this step's MFMAs
+  // one K step: the next step's fragments and the weight tile three steps ahead are in flight under this step's MFMAs.  The
+  // LDS-DMA goes out between the two MFMA halves (slot g % NS is free since the barrier that ended step g - 1): next to the burst
+  // of fragment reads at the top of the step its issue cost the wave 2-3x as much
   auto step = [&](Frags& cur, Frags& nxt, bool isB, int sidx, int n, int g) {
-    issue_dma(g + 3);
     const bool more = sidx + 1 < n;
     if (more) load_frags(nxt, isB, sidx + 1, g + 1);
-    mfma_block(cur);
+    mfma_half(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_dma(g + 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_half(cur, 1);
     if (more) pair_settle(nxt);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");      // tile g+2 has landed (tile g+3 may still be in flight)
     __builtin_amdgcn_s_barrier();
