@@ -90,6 +90,8 @@ _SIGS = {
     "dmx_flash_attn_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p]),
     "dmx_gemm_splitk_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dmx_conv_pair_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_groupnorm_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "dmx_groupnorm_raw": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_destroy": (None, [C.c_void_p]),

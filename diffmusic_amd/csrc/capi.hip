@@ -127,4 +127,12 @@ int dmx_gemm_splitk_workspace(void* ws, size_t bytes) {
   return DMX_OK;
 }
 
+size_t dmx_groupnorm_scratch_floats(int B, int C, int G) { return dmx_gn_scratch_floats(B, C, G); }
+int dmx_groupnorm_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
+                      float* partial, int B, int P, int C, int G, float eps, int silu, void* stream) {
+  const int rc = dmx_groupnorm_fwd((const act_t*)x, (act_t*)y, gamma, beta, stats, scale, shift, partial, B, P, C, G, eps, silu, ST(stream));
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("groupnorm: unsupported channel / group counts");
+  return rc;
+}
+
 }  // extern "C"

@@ -115,7 +115,7 @@ struct GemmDesc {
   int flags;
   signed char tdy[DMX_MAX_TAPS], tdx[DMX_MAX_TAPS];
   float resid_inv_slope;
-  int tile_cfg;          // 0 = automatic; 1..6 force a tile configuration (tuning hook)
+  int tile_cfg;          // 0 = automatic; 1..18 force a tile configuration, 100 * slices + tile a split-K plan (tuning hook)
   int ldrb;              // row stride of rowbias in floats (0 = N); > N when it is a slice of a batched projection
   int ksplit;            // internal: > 1 = this launch is one K slice per blockIdx.z writing fp32 partials (set by the dispatcher)
   const unsigned char* XB;   // EPI_MASKBITS source, row stride ldxb bytes (rows indexed like C; Z must be 1)

@@ -209,6 +209,121 @@ __global__ void gn_apply_kernel(const act_t* __restrict__ x, const float* __rest
   for (; p < p1; p += rpb) body(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), base + (long long)p * C);
 }
 
+// Two-launch GroupNorm for the mid-size U-Net levels (1000 .. 4000 pixels): gn_partial_kernel<0> as above, then this kernel, whose
+// prologue combines the (at most GN_FUSED_MAXCHUNK) chunk partials of its image -- the same Chan combine gn_finalize_kernel does --
+// and keeps scale / shift of all channels in LDS.  Every workgroup repeats the tiny combine (<= 8 KB of partials from L2), which
+// is cheaper than a third launch; workgroup 0 of an image also writes stats / scale / shift for callers that keep a tape.
+constexpr int GN_FUSED_MAXCHUNK = 32;
+__global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const act_t* __restrict__ x, const float* __restrict__ partial,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float* __restrict__ stats, float* __restrict__ scale, float* __restrict__ shift,
+                                         act_t* __restrict__ y, int P, int C, int G, int nchunk, int rpb, int ppb, float eps, int silu) {
+  __shared__ float s_red[GN_FUSED_MAXCHUNK][64];
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
+  const int cpr = C >> 3;
+  const int col = tid % cpr, row = tid / cpr, c0 = col << 3;
+  const bool active = row < rpb;
+  const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+  const long long base = (long long)b * P * C + c0;
+  // everything that does not depend on the statistics is requested first: this thread's affine parameters, its first rows, and
+  // the chunk partials (at most 8 (chunk, group) slots per thread), so that one memory round trip
+  // covers the whole prologue
+  float ga[8], be[8];
+  uint4 xv0[4];
+  int p = p0 + row;
+  const bool first4 = active && p + 3 * rpb < p1;
+  if (active) {
+    const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    ga[0] = g0.x; ga[1] = g0.y; ga[2] = g0.z; ga[3] = g0.w; ga[4] = g1.x; ga[5] = g1.y; ga[6] = g1.z; ga[7] = g1.w;
+    be[0] = b0.x; be[1] = b0.y; be[2] = b0.z; be[3] = b0.w; be[4] = b1.x; be[5] = b1.y; be[6] = b1.z; be[7] = b1.w;
+    if (first4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv0[u] = *reinterpret_cast<const uint4*>(x + base + (long long)(p + u * rpb) * C);
+    }
+  }
+  constexpr int PV_MAX = 8;                       // the launcher keeps nchunk * G <= 8 * blockDim
+  float2 pv[PV_MAX];
+  const int nslots = nchunk * G, nth = blockDim.x;
+#pragma unroll
+  for (int q = 0; q < PV_MAX; ++q) {
+    const int i = tid + q * nth;
+    pv[q] = make_float2(0.f, 0.f);
+    if (i < nslots) pv[q] = *reinterpret_cast<const float2*>(partial + ((long long)b * nslots + i) * 2);   // slot i = (chunk i / G, group i % G)
+  }
+#pragma unroll
+  for (int q = 0; q < PV_MAX; ++q) {
+    const int i = tid + q * nth;
+    if (i < nslots) {
+      const int k = i / G, g = i - k * G;
+      const float nb = (float)(min(P, (k + 1) * ppb) - k * ppb) * cpg;
+      s_red[k][g] = nb * pv[q].x;
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    float sw = 0.f;
+    for (int k = 0; k < nchunk; ++k) sw += s_red[k][tid];
+    s_mean[tid] = sw / ((float)P * cpg);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PV_MAX; ++q) {
+    const int i = tid + q * nth;
+    if (i < nslots) {
+      const int k = i / G, g = i - k * G;
+      const float nb = (float)(min(P, (k + 1) * ppb) - k * ppb) * cpg;
+      const float d = pv[q].x - s_mean[g];
+      s_red[k][g] = pv[q].y + nb * d * d;
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    float m2 = 0.f;
+    for (int k = 0; k < nchunk; ++k) m2 += s_red[k][tid];
+    const float rstd = rsqrtf(m2 / ((float)P * cpg) + eps);
+    s_rstd[tid] = rstd;
+    if (blockIdx.x == 0) { stats[((long long)b * G + tid) * 2] = s_mean[tid]; stats[((long long)b * G + tid) * 2 + 1] = rstd; }
+  }
+  __syncthreads();
+  if (!active) return;
+  float sc[8], sf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int gg = (c0 + i) / cpg;
+    sc[i] = s_rstd[gg] * ga[i];
+    sf[i] = be[i] - s_mean[gg] * sc[i];
+  }
+  if (blockIdx.x == 0 && row == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { scale[(long long)b * C + c0 + i] = sc[i]; shift[(long long)b * C + c0 + i] = sf[i]; }
+  }
+  auto body = [&](const uint4& xv, long long off) {
+    float f[8];
+    unpack8(xv, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = f[i] * sc[i] + sf[i];
+      f[i] = silu ? silu_f(z) : z;
+    }
+    *reinterpret_cast<uint4*>(y + off) = pack8(f);
+  };
+  if (first4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(xv0[u], base + (long long)(p + u * rpb) * C);
+    p += 4 * rpb;
+  }
+  for (; p + 3 * rpb < p1; p += 4 * rpb) {
+    uint4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const uint4*>(x + base + (long long)(p + u * rpb) * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(xv[u], base + (long long)(p + u * rpb) * C);
+  }
+  for (; p < p1; p += rpb) body(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), base + (long long)p * C);
+}
+
 // backward finalize: per (b,c) coefficients k0, k1 with dx = scale*dy*act'(z) + k0 + k1*x
 __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
                                        float* __restrict__ k0, float* __restrict__ k1,
@@ -736,13 +851,30 @@ int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
                       float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st) {
   if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
   const int cpg = C / G;
-  static const bool small_ok = getenv("DMX_NO_GN_SMALL") == nullptr;
-  if (small_ok && (cpg & 3) == 0 && cpg <= 256 && (long long)P * (cpg >> 2) <= 256ll * GN_SMALL_MAXU && (long long)B * G >= 128) {
+  static const bool small_ok = getenv("DMX_NO_GN_SMALL") == nullptr, fused_ok = getenv("DMX_NO_GN_FUSED") == nullptr;
+  // one workgroup per (group, image) holds its slice in registers: one launch, but its 8-byte pieces of 2C-byte rows are the
+  // worst case for the memory pipeline -- it wins only where the tensor is tiny (<= 512 pixels: launch latency rules)
+  const bool small_fits = (cpg & 3) == 0 && cpg <= 256 && (long long)P * (cpg >> 2) <= 256ll * GN_SMALL_MAXU && (long long)B * G >= 128;
+  const bool mid = y && fused_ok && P >= 512 && P <= 8192 && (C >> 3) <= 256;
+  if (small_ok && small_fits && !mid) {
     hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, st, x, y, gamma, beta, stats, scale, shift, P, C, G, eps, silu);
     return CHECK_LAUNCH();
   }
   int nt, rpb, nchunk, ppb;
   gn_geom(P, C, nt, rpb, nchunk, ppb);
+  if (mid) {
+    // mid-size images: row-coalesced statistics, then finalize + apply in one launch (at most GN_FUSED_MAXCHUNK chunks per image)
+    const int nt2 = nt < 64 ? 64 : nt;
+    int cmax = GN_FUSED_MAXCHUNK;
+    while (cmax > 1 && cmax * G > 8 * nt2) --cmax;
+    if (nchunk > cmax) { nchunk = cmax; ppb = cdiv(P, nchunk); nchunk = cdiv(P, ppb); }
+    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
+                       (const act_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial,
+                       P, C, G, rpb, ppb, 0);
+    hipLaunchKernelGGL(gn_finalize_apply_kernel, dim3(nchunk, B), dim3(nt2), 0, st, x, partial, gamma, beta,
+                       stats, scale, shift, y, P, C, G, nchunk, rpb, ppb, eps, silu);
+    return CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x,
                      (const act_t*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial,
                      P, C, G, rpb, ppb, 0);

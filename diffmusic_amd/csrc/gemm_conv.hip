@@ -18,6 +18,9 @@
 namespace {
 
 constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
+#ifndef DMX_DEF_BIG
+#define DMX_DEF_BIG 0      // fragment steps the lagging half of the register-bound 320-row tiles carries across the barrier (0 = no stagger there)
+#endif
 
 
 template <int BM, int BN, int WM, int WN, bool BITS>
@@ -470,6 +473,11 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 12: return launch_glds<64, 64, 2, 2, 4>(d, stream);
     case 13: return launch_glds<128, 64, 2, 2, 3>(d, stream);
     case 14: return launch_glds<64, 128, 2, 2, 3>(d, stream);
+    // deep rings for the latency-bound small-M launches (one workgroup per CU, the whole K panel of a short GEMM in flight at once)
+    case 15: return launch_glds<64, 64, 2, 2, 8>(d, stream);
+    case 16: return launch_glds<64, 128, 2, 2, 6>(d, stream);
+    case 17: return launch_glds<128, 64, 2, 2, 6>(d, stream);
+    case 18: return launch_glds<128, 128, 2, 2, 4>(d, stream);
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -479,7 +487,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 14 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
     static int ovN[8], ovC[8], nov = -1;
     if (nov < 0) {
@@ -498,7 +506,10 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   }
   // measured best configuration for the shapes of the shipped benchmark configs (scripts/dev/tune_tiles.py)
   for (const TileEntry* e = g_tile_table; e->cfg; ++e)
-    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z && ((e->cfg > 2 && e->cfg < 7) || gl)) return launch_by_cfg(e->cfg, d, stream);
+    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z) {
+      const int c = e->cfg % 100;                  // (hundreds = a split-K plan, taken by splitk_plan when the launch allows it)
+      if ((c > 2 && c < 7) || gl) return launch_by_cfg(c, d, stream);
+    }
   if (gl && d.M >= 2048 && d.N % 128 == 0) {
     // otherwise pick the tile that minimises (rounds over the 256 CUs) x (time per block); efficiencies measured on MI355X
     auto cost = [&](int bm, int bn, int slots, double eff) {
@@ -623,35 +634,49 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
   }
 }
 
-// returns the number of K slices to use for `d` (1 = no split)
-int splitk_plan(const GemmDesc& d) {
+// returns the number of K slices to use for `d` (1 = no split) and the tile configuration of the slices.  A plan comes from
+// (i) the tuning hook tile_cfg = 100 * slices + tile, (ii) the measured table (same encoding), (iii) the heuristic below.
+int splitk_plan(const GemmDesc& d, int* tile) {
   static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
-  if (off || !g_splitk_ws || d.Z != 1 || d.tile_cfg || !glds_ok(d)) return 1;
+  if (off || !g_splitk_ws || d.Z != 1 || !glds_ok(d)) return 1;
   if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2)) return 1;
   if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
-  if ((d.N & 7) || (d.ldc & 3) || d.M > 8192) return 1;
+  if ((d.N & 7) || (d.ldc & 3)) return 1;
   const int nk = (d.K + BK - 1) / BK;
+  auto fits = [&](int ks) { return ks >= 2 && ks <= nk && (size_t)ks * d.M * d.N * sizeof(float) <= g_splitk_bytes; };
+  auto dma_tile = [](int t) { return t == 1 || t == 2 || (t >= 7 && t <= 18); };      // only the LDS-DMA kernel walks a K slice
+  if (d.tile_cfg >= 100) { *tile = d.tile_cfg % 100; return fits(d.tile_cfg / 100) && dma_tile(*tile) ? d.tile_cfg / 100 : 1; }
+  if (d.tile_cfg) return 1;
+  for (const TileEntry* e = g_tile_table; e->cfg; ++e)
+    if (e->M == d.M && e->N == d.N && e->K == d.K && e->Z == d.Z) {
+      if (e->cfg < 100) return 1;
+      *tile = e->cfg % 100;
+      return fits(e->cfg / 100) && dma_tile(*tile) ? e->cfg / 100 : 1;
+    }
+  if (d.M > 8192) return 1;
   const long long tiles = (long long)cdiv(d.M, 64) * cdiv(d.N, 64);
   if (nk < 24 || tiles >= 256) return 1;        // only when the tile grid cannot fill the 256 CUs (measured: 378 tiles x 2 slices is slower)
   int ks = (int)(1024 / tiles);                 // aim at ~4 workgroups per CU
   if (ks > nk / 8) ks = nk / 8;                 // at least 8 K steps per slice
   if (ks > 8) ks = 8;
-  while (ks > 1 && (size_t)ks * d.M * d.N * sizeof(float) > g_splitk_bytes) --ks;
+  while (ks > 1 && !fits(ks)) --ks;
+  *tile = d.N % 128 == 0 && d.M >= 4096 ? 14 : 12;
   return ks < 2 ? 1 : ks;
 }
 
-int launch_splitk(const GemmDesc& d, int ks, hipStream_t stream) {
+int launch_splitk(const GemmDesc& d, int ks, int tile, hipStream_t stream) {
   GemmDesc g = d;
   g.ksplit = ks;
   g.flags = EPI_F32OUT;
   g.C = g_splitk_ws; g.C2 = nullptr; g.ldc = d.N; g.alpha = 1.f;
   g.bias = nullptr; g.rowbias = nullptr; g.R = nullptr; g.X = nullptr;
   g.Ho = d.Hq; g.Wo = d.Wq;
-  int rc = launch_by_cfg(d.N % 128 == 0 && d.M >= 4096 ? 14 : 12, g, stream);
+  g.tile_cfg = 0;
+  int rc = launch_by_cfg(tile, g, stream);
   if (rc != DMX_OK) return rc;
   const long long nthr = (long long)d.M * (d.N >> 2);
   hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, d, g_splitk_ws, ks);
-  g_last_cfg = 40 + ks;
+  g_last_cfg = 100 * ks + tile;
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 }  // namespace
@@ -692,8 +717,10 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
     if ((d.flags & EPI_MASKBITS) && (!d.XB || d.ldxb * 8 < d.N)) return DMX_ERR_SHAPE;
     if ((d.flags & EPI_BITS2) && (!d.B2 || d.ldb2 * 8 < d.N)) return DMX_ERR_SHAPE;
   }
-  const int ksp = splitk_plan(d);
-  if (!g_prof) return ksp > 1 ? launch_splitk(d, ksp, stream) : launch_dispatch(d, stream);
+  int ktile = 12;
+  const int ksp = splitk_plan(d, &ktile);
+  if (ksp <= 1 && d.tile_cfg >= 100) return DMX_ERR_SHAPE;          // a forced split-K plan this launch cannot take (tuning hook)
+  if (!g_prof) return ksp > 1 ? launch_splitk(d, ksp, ktile, stream) : launch_dispatch(d, stream);
   ProfRec r;
   (void)hipEventCreate(&r.a); (void)hipEventCreate(&r.b);
   r.flops = 2.0 * d.M * (double)d.N * d.K * d.Z;
@@ -711,7 +738,7 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   }
   r.M = d.M; r.N = d.N; r.K = d.K; r.Z = d.Z; r.taps = d.ntaps; r.flags = d.flags;
   (void)hipEventRecord(r.a, stream);
-  const int rc = ksp > 1 ? launch_splitk(d, ksp, stream) : launch_dispatch(d, stream);
+  const int rc = ksp > 1 ? launch_splitk(d, ksp, ktile, stream) : launch_dispatch(d, stream);
   (void)hipEventRecord(r.b, stream);
   r.cfg = g_last_cfg;
   g_prof_recs.push_back(r);

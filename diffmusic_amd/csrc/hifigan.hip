@@ -14,8 +14,18 @@
 #include "conv_pair.h"
 #include <cstdlib>
 
+// installs a model-owned split-K scratch for the launches of one executor call and removes it on every return path
+struct SplitKScope {
+  explicit SplitKScope(float* ws, size_t bytes, bool on) : on_(on && ws) { if (on_) dmx_gemm_set_splitk_workspace(ws, bytes); }
+  ~SplitKScope() { if (on_) dmx_gemm_set_splitk_workspace(nullptr, 0); }
+  bool on_;
+};
+
 struct HifiGan : Model {
   dmx_hifigan_config cfg;
+  // fp32 partial tiles for the few small-M / deep-K launches of the vocoder (conv_pre and its dgrad: M = B * frames, K = 7 * C0)
+  static constexpr size_t kSplitKBytes = 32u << 20;
+  float* splitk_ws = nullptr;
   ConvLayer conv_pre, conv_post;
   std::vector<ConvLayer> ups;
   std::vector<ConvLayer> c1, c2;  // [stage][kernel][dil] flattened
@@ -41,6 +51,7 @@ struct HifiGan : Model {
   bool want_multi = true;
   hipEvent_t next_event() { hipEvent_t e = events[ev_next]; ev_next = (ev_next + 1) % events.size(); return e; }
   bool multi() const { return want_multi && !dry && !dmx_prof_is_active() && nk > 1; }
+  bool multi_wanted() const { return want_multi && nk > 1; }      // (the one shared split-K scratch is for single-stream schedules only)
 
   int idx(int s, int k, int d) const { return (s * nk + k) * nd + d; }
 
@@ -73,8 +84,10 @@ struct HifiGan : Model {
     for (int k = 1; k < nk; ++k) (void)hipStreamCreateWithFlags(&bstream[k], hipStreamNonBlocking);
     events.resize(256);
     for (auto& e : events) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    splitk_ws = (float*)ps.dalloc(kSplitKBytes);
   }
   ~HifiGan() override {
+    dmx_gemm_release_splitk_workspace(splitk_ws);
     for (int k = 1; k < nk; ++k) if (bstream[k]) (void)hipStreamDestroy(bstream[k]);
     for (auto& e : events) (void)hipEventDestroy(e);
   }
@@ -112,6 +125,7 @@ struct HifiGan : Model {
   int forward(const act_t* mel, float* wav, int B_, int T_, void* ws, size_t ws_bytes, hipStream_t st) {
     if (cfg.model_in_dim & 7) return DMX_ERR_SHAPE;
     dry = (ws == nullptr);
+    SplitKScope sk_scope(splitk_ws, kSplitKBytes, !dry && !multi_wanted());
     arena.reset(ws, dry ? (size_t)-1 : ws_bytes);
     B = B_; T = T_;
     Ts.assign(ns, 0);
@@ -221,6 +235,7 @@ struct HifiGan : Model {
   // dwav: (B, Tout) fp32 -> dmel: (B, T, model_in_dim) bf16.  Uses the tape of the last forward.
   int backward(const float* dwav, act_t* dmel, hipStream_t st) {
     if (!have_tape && !dry) { dmx_set_error("hifigan backward without forward"); return DMX_ERR_STATE; }
+    SplitKScope sk_scope(splitk_ws, kSplitKBytes, !dry && !multi_wanted());
     const float slope = cfg.leaky_relu_slope;
     const int Tout = Ts[ns - 1];
     const size_t mk0 = arena.mark();

@@ -206,6 +206,12 @@ int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, co
  * installs its own */
 int dmx_gemm_splitk_workspace(void* ws, size_t bytes);
 int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes, void* stream);
+/* test hook: GroupNorm (+ SiLU) forward as the U-Net / VAE executors run it (diffusers ResnetBlock2D norm1 / norm2, Attention
+ * group_norm; reached from pipeline_musicldm.py:696-703 and scheduling_dps.py:195-197).  x, y (B, P, C) fp16 channels-last;
+ * stats (B, G, 2) = (mean, rstd), scale / shift (B, C) fp32 outputs; partial: fp32 scratch of dmx_groupnorm_scratch_floats(B, C, G). */
+size_t dmx_groupnorm_scratch_floats(int B, int C, int G);
+int dmx_groupnorm_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
+                      float* partial, int B, int P, int C, int G, float eps, int silu, void* stream);
 
 #ifdef __cplusplus
 }

@@ -104,7 +104,7 @@ def test_batched_nt_gemm_f32_out_and_mask():
     assert _rel(outb, ref) < 6e-3
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
 def test_forced_tile_configs_agree(cfg):
     """every tile configuration (incl. the 320x256 LDS-DMA tile) gives the same conv result"""
     from diffmusic_amd import _lib as L
@@ -257,6 +257,33 @@ def test_split_k_small_m_conv(B, H, W, Ci, Co):
     ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1) + rowb[:, None, None, :] + res.float()
     assert _rel(outs[1], ref) < 3e-3
     assert _rel(outs[0], ref) < 3e-3
+    assert _rel(outs[1], outs[0]) < 2e-3
+
+
+@pytest.mark.parametrize("plan", [212, 313, 414, 611, 815, 318, 202])
+def test_forced_split_k_plans_agree(plan):
+    """tile_cfg = 100 * slices + tile forces a split-K plan (what the measured table stores): every plan gives the single-pass result"""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(11)
+    B, H, W, Ci, Co = 8, 16, 16, 384, 384
+    x = torch.randn(B, H, W, Ci, generator=g).to(_adt()).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5).to(_adt()).cuda()
+    wp = w.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).contiguous()
+    bias = torch.randn(Co, generator=g).cuda()
+    res = torch.randn(B, H, W, Co, generator=g).to(_adt()).cuda()
+    scratch = torch.empty(32 << 20, dtype=torch.float32, device="cuda")
+    L.check(L.lib().dmx_gemm_splitk_workspace(C.c_void_p(scratch.data_ptr()), scratch.numel() * 4), "ws")
+    outs = []
+    for cfg in (6, plan):
+        out = torch.zeros(B, H, W, Co, dtype=_adt(), device="cuda")
+        d = _desc(L, A=x, W=wp, C=out, bias=bias, R=res, M=B * H * W, N=Co, K=9 * Ci, ldw=9 * Ci, Hi=H, Wi=W, Ci=Ci, lda=Ci,
+                  Hq=H, Wq=W, ntaps=9, Ho=H, Wo=W, ldc=Co, ldr=Co, ldx=Co, ldc2=Co, flags=L.EPI_BIAS | L.EPI_RESID,
+                  tdy=[t // 3 - 1 for t in range(9)], tdx=[t % 3 - 1 for t in range(9)], tile_cfg=cfg)
+        _run(L, d)
+        outs.append(out)
+    L.check(L.lib().dmx_gemm_splitk_workspace(None, 0), "ws")
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias, padding=1).permute(0, 2, 3, 1) + res.float()
+    assert _rel(outs[1], ref) < 3e-3
     assert _rel(outs[1], outs[0]) < 2e-3
 
 
