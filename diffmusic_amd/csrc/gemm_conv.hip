@@ -19,7 +19,7 @@ namespace {
 
 constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
 #ifndef DMX_DEF_BIG
-#define DMX_DEF_BIG 0      // fragment steps the lagging half of the register-bound 320-row tiles carries across the barrier (0 = no stagger there)
+#define DMX_DEF_BIG 4      // fragment steps the lagging half of the register-bound 320-row tiles carries across the barrier (0 = no stagger there; 4 is what its 256 registers hold)
 #endif
 
 
@@ -192,7 +192,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int nsplit = p.ksplit > 1 ? p.ksplit : 1, sp = blockIdx.z;     // split-K: this workgroup owns K steps [ks0, ks1)
   const long long coff = zo * p.sCo + zi * p.sCi + (nsplit > 1 ? (long long)sp * p.M * p.N : 0ll);
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Ab), 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, OOB, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<act_t*>(Wb), 0, (unsigned)p.N * (unsigned)p.ldw * 2u, 0x00020000);
 
   // tap table in a REGISTER: lane j (< 16) holds (dy, dx) of tap j, looked up with v_readlane / ds_bpermute.  It must not live
   // in LDS: the compiler puts an s_waitcnt vmcnt(0) in front of every LDS read it can see (it may alias an in-flight LDS-DMA
@@ -207,29 +207,33 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int cpt = p.Ci >> 3;
   const int HqWq = p.Hq * p.Wq;
   const unsigned lda2 = (unsigned)p.lda * 2u;
-  unsigned a_boff[A_ISS], a_lin[A_ISS];
-  int a_iy[A_ISS], a_ix[A_ISS];
+  // per fetched row: byte offset of its chunk at tap (0, 0) / channel group 0, and a 16-bit mask of the taps that fall inside the
+  // input for this row (conv zero padding, rows past M: mask 0) -- two masks per register.  The K loop then needs one bit test
+  // per row and step instead of two coordinate adds and two range compares, and 3 instead of 10 registers for A_ISS = 5.
+  unsigned a_lin[A_ISS], a_mask2[(A_ISS + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < (A_ISS + 1) / 2; ++i) a_mask2[i] = 0u;
 #pragma unroll
   for (int i = 0; i < A_ISS; ++i) {
     const int m = m0 + (i * NW + wave) * 8 + lrow;
+    unsigned mask = 0u;
+    a_lin[i] = 0u;
     if (m < p.M) {
       const int b = m / HqWq, rem = m - b * HqWq;
       const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-      a_boff[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * lda2;
-      a_iy[i] = qy * p.sy;
-      a_ix[i] = qx * p.sx;
-    } else {
-      a_boff[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;
-    }
-    // byte offset of this lane's chunk at tap (0, 0), channel group 0 (meaningless for an out-of-range row: its iy test fails)
-    a_lin[i] = a_boff[i] + (unsigned)(a_iy[i] * p.Wi + a_ix[i]) * lda2 + ((unsigned)cc << 4);
-  }
-  unsigned w_off[B_ISS];
+      const int iy = qy * p.sy, ix = qx * p.sx;
+      a_lin[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * lda2 + (unsigned)(iy * p.Wi + ix) * lda2 + ((unsigned)cc << 4);
 #pragma unroll
-  for (int i = 0; i < B_ISS; ++i) {
-    const int n = tn * BN + (i * NW + wave) * 8 + lrow;
-    w_off[i] = n < p.N ? (unsigned)n * (unsigned)p.ldw * 2u : OOB;
+      for (int t = 0; t < DMX_MAX_TAPS; ++t)
+        if (t < p.ntaps && (unsigned)(iy + p.tdy[t]) < (unsigned)p.Hi && (unsigned)(ix + p.tdx[t]) < (unsigned)p.Wi) mask |= 1u << t;
+    }
+    a_mask2[i >> 1] |= mask << ((i & 1) * 16);
   }
+  // weight rows: instruction j fetches row tn * BN + (j * NW + wave) * 8 + lrow; rows past N lie beyond the descriptor's range
+  // (num_records = N rows) and come back as zeros
+  const unsigned ldw2 = (unsigned)p.ldw * 2u;
+  const unsigned w_row = (unsigned)(tn * BN + wave * 8 + lrow) * ldw2;
+  const unsigned w_step = (unsigned)(NW * 8) * ldw2;
 
   const int kchunks = p.K >> 3;
   // K order: with Ci % 64 == 0 a K-step is one (tap, 64-channel group); walk the taps innermost so the ~(BM + halo)
@@ -246,7 +250,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // issued back to back with seven others and a burst of ds_reads costs the wave 100-185 cycles, one slipped between MFMA groups
   // 25-60; MI355X_MICROARCH.md): issue_begin() computes what depends on the K step only, issue_one<I>() sends instruction I.
   bool q_kval = false;          // this lane's chunk of the step exists (K tail, split-K range, partial last channel group)
-  int q_dy = 0, q_dx = 0;
+  int q_tp = 0;                 // tap of this lane's chunk (wave-uniform on the tap-inner walk)
   unsigned q_adel = 0, q_wdel = 0;   // byte deltas added to the per-row A offsets / weight-row offsets
   char* q_base = nullptr;
   auto issue_begin = [&](int ksl, int stage) {
@@ -256,8 +260,9 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       const int tp = __builtin_amdgcn_readfirstlane(i_tp), cgi = __builtin_amdgcn_readfirstlane(i_cg);
       q_kval = cgi < cgroups && ksl + ks0 < ks1 && cgi * 8 + cc < cpt;     // (lane term: partial last group when Ci % 64 != 0)
       const int tv = __builtin_amdgcn_readlane(tapreg, tp);
-      q_dy = (int)(signed char)(tv & 0xff); q_dx = (int)(signed char)((tv >> 8) & 0xff);
-      q_adel = (unsigned)((q_dy * p.Wi + q_dx) * (int)lda2) + ((unsigned)cgi << 7);       // tap shift + 64-channel group, bytes
+      const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
+      q_tp = tp;
+      q_adel = (unsigned)((dy * p.Wi + dx) * (int)lda2) + ((unsigned)cgi << 7);           // tap shift + 64-channel group, bytes
       q_wdel = (unsigned)(tp * cpt + cgi * 8 + cc) << 4;                                      // weight-row byte offset of this chunk
       if (++i_tp == p.ntaps) { i_tp = 0; ++i_cg; }
     } else {
@@ -266,20 +271,21 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       const int tap = kc / cpt;
       q_kval = kc < kchunks && ks < ks1;
       const int tv = __builtin_amdgcn_ds_bpermute((tap & (DMX_MAX_TAPS - 1)) << 2, tapreg);
-      q_dy = (int)(signed char)(tv & 0xff); q_dx = (int)(signed char)((tv >> 8) & 0xff);
-      q_adel = (unsigned)((q_dy * p.Wi + q_dx) * (int)lda2) + ((unsigned)(kc - tap * cpt) << 4) - ((unsigned)cc << 4);   // a_lin already holds cc * 16
+      const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
+      q_tp = tap & (DMX_MAX_TAPS - 1);
+      q_adel = (unsigned)((dy * p.Wi + dx) * (int)lda2) + ((unsigned)(kc - tap * cpt) << 4) - ((unsigned)cc << 4);   // a_lin already holds cc * 16
       q_wdel = (unsigned)kc << 4;
     }
   };
   auto issue_one = [&](auto I) {
     constexpr int i = decltype(I)::value;
     if constexpr (i < A_ISS) {
-      const bool ok = q_kval && (unsigned)(a_iy[i] + q_dy) < (unsigned)p.Hi && (unsigned)(a_ix[i] + q_dx) < (unsigned)p.Wi;
+      const bool ok = q_kval && ((a_mask2[i >> 1] >> ((i & 1) * 16 + q_tp)) & 1u);
       const unsigned voff = ok ? a_lin[i] + q_adel : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(q_base + (i * NW + wave) * 1024), 16, voff, 0, 0, 0);
     } else {
       constexpr int j = i - A_ISS;
-      const unsigned voff = (q_kval && w_off[j] != OOB) ? w_off[j] + q_wdel : OOB;
+      const unsigned voff = q_kval ? w_row + (unsigned)j * w_step + q_wdel : OOB;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(q_base + A_BYTES + (j * NW + wave) * 1024), 16, voff, 0, 0, 0);
     }
   };
@@ -304,38 +310,80 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
-  int cur = 0, nxt = NSTAGE - 1;
-  for (int ks = 0; ks < nk; ++ks) {
-    const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
-    const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
-    {
-      // Hand-scheduled fragment pipeline.  hipcc sinks every ds_read next to its consumer (read 2, wait, 4-8 MFMAs: the LDS
-      // latency is exposed 16x per K-step and the matrix pipe idles ~50 %).  Here the reads are inline asm issued two steps
-      // (2*FN MFMAs) ahead of their use, with counted lgkmcnt waits computed at compile time from the issue order (LDS
-      // returns in order), and sched_barrier fences so the MFMAs of a step cannot be hoisted above its wait.
-      constexpr int NS = 2 * FM;                                   // steps per K-step: (kk, i), FN MFMAs each
-      constexpr int P0 = FN + 2;                                   // prologue reads: wf0[0..FN), af[0], af[1]
+
+  // Hand-scheduled fragment pipeline.  hipcc sinks every ds_read next to its consumer (read 2, wait, 4-8 MFMAs: the LDS
+  // latency is exposed 16x per K-step and the matrix pipe idles ~50 %).  Here the reads are inline asm issued two steps
+  // (2*FN MFMAs) ahead of their use, with counted lgkmcnt waits computed at compile time from the issue order (LDS
+  // returns in order), and sched_barrier fences so the MFMAs of a step cannot be hoisted above its wait.
+  //
+  // Stagger (8-wave tiles: two waves per SIMD that run the same program with one barrier per K step): left alone the two
+  // partners move in lockstep -- both wait for their first fragments behind the barrier, both compute addresses, both issue
+  // LDS-DMA at the same time, and the matrix pipe idles through all of it.  The second-dispatched half of the workgroup
+  // (waves NW/2 ..) therefore runs up to HALF A K STEP BEHIND: between two barriers it first issues the last DEF fragment steps
+  // (all kk = 1) of the previous K step -- their fragments were read, and waited for, before the barrier and stay in registers
+  // across it -- with the LDS-DMA issues and the new stage's first reads underneath, then the first NS - DEF steps of the
+  // current K step, during which it also reads the fragments it will carry across the next barrier.  Its partner's exposed
+  // latency behind the barrier is covered by the carried MFMAs and vice versa.  Per-wave accumulation order is unchanged:
+  // results are bit-identical to the unstaggered schedule (MI355X_MICROARCH.md, two waves per SIMD, item 9).
+  constexpr int NS = 2 * FM;                                   // steps per K-step: (kk, i), FN MFMAs each
+  constexpr int P0 = FN + 2;                                   // prologue reads: wf0[0..FN), af[0], af[1]
+  // DEF = fragment steps the lagging half carries across the barrier: half a K step where the registers allow it (4 * DEF +
+  // 4 * FN carried VGPRs next to the FM * FN * 4 accumulators), DMX_DEF_BIG on the register-bound 320-row tile
+  constexpr bool ROOMY = FM * FN * 4 + 4 * FM + 8 * FN + 64 <= 256;
+  constexpr bool STAGGER = NW == 8 && FM >= 2 && (ROOMY || DMX_DEF_BIG > 0);
+  constexpr int DEF = ROOMY ? FM : (DMX_DEF_BIG > 0 ? (DMX_DEF_BIG < FM ? DMX_DEF_BIG : FM) : 1);
+  constexpr int LOWN = NS - DEF;                               // steps of the current K step the lagging half runs before the barrier
+  static_assert(DEF <= FM && DEF >= 1, "carried steps must all be kk = 1 steps");
+  frag8_t wf0[FN], wf1[FN], af[NS];
+#define DMX_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  auto kloop = [&](auto LAGT) {
+    constexpr bool LAG = decltype(LAGT)::value;
+    int cur = 0, nxt = NSTAGE - 1;
+    auto mfma_step = [&wf0, &wf1, &af, &acc](auto ST) {
+      constexpr int st = decltype(ST)::value;
+      constexpr int kk = st / FM, i = st - kk * FM;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int ks = 0; ks < nk; ++ks) {
+      const char* sa = smem + cur * STAGE + (wm * TM + lr) * 128;
+      const char* sb = smem + cur * STAGE + A_BYTES + (wn * TN + lr) * 128;
       const unsigned a0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(sa);
       const unsigned b0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(sb);
       const unsigned sw0 = ((0 * 4 + lq) ^ (lr & 7)) << 4, sw1 = ((1 * 4 + lq) ^ (lr & 7)) << 4;
       const unsigned aA0 = a0 + sw0, aA1 = a0 + sw1, aB0 = b0 + sw0, aB1 = b0 + sw1;
-      frag8_t wf0[FN], wf1[FN], af[NS];
-#define DMX_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-      static_for<0, FN>([&wf0, aB0](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf0[j], aB0, j * 2048); });
-      DMX_DSR(af[0], aA0, 0);
-      if constexpr (FM > 1) { DMX_DSR(af[1], aA0, 2048); } else { DMX_DSR(af[1], aA1, 0); }
-      auto frag_step = [&wf0, &wf1, &af, &acc, aA0, aA1, aB1](auto ST) {
+      __builtin_amdgcn_sched_barrier(0);
+      // (register-bound tiles: the lagging half reads its first fragments only AFTER the carried MFMAs, whose operands then die first)
+      constexpr bool P0_LATE = LAG && DEF < FM;
+      auto prologue_reads = [&wf0, &af, aA0, aA1, aB0]() {
+        static_for<0, FN>([&wf0, aB0](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf0[j], aB0, j * 2048); });
+        DMX_DSR(af[0], aA0, 0);
+        if constexpr (FM > 1) { DMX_DSR(af[1], aA0, 2048); } else { DMX_DSR(af[1], aA1, 0); }
+      };
+      if constexpr (!P0_LATE) prologue_reads();
+      // reads of fragment step st: af of step st + 2; the kk = 1 weights trickle in during kk = 0; the lagging half's last DEF - 2
+      // own steps also fetch af[LOWN + 2 ..] (every fragment it carries must be in registers before the barrier)
+      auto read_step = [&wf1, &af, aA0, aA1, aB1](auto ST) {
         constexpr int st = decltype(ST)::value;
-        constexpr bool pre_a = st + 2 < NS;
-        // weights of kk = 1 trickle in during kk = 0: step st (< FM) fetches wf1[j] for j in [st*FN/FM, (st+1)*FN/FM)
-        constexpr int w_lo = st < FM ? st * FN / FM : 0, w_hi = st < FM ? (st + 1) * FN / FM : 0;
-        if constexpr (pre_a) {
+        if constexpr (st + 2 < NS) {
           constexpr int s2 = st + 2, k2 = s2 / FM, i2 = s2 - k2 * FM;
           if constexpr (k2 == 0) { DMX_DSR(af[s2], aA0, i2 * 2048); } else { DMX_DSR(af[s2], aA1, i2 * 2048); }
         }
+        if constexpr (LAG && st >= LOWN - (DEF - 2) && st < LOWN) {
+          constexpr int s3 = st + DEF, i3 = s3 - FM;
+          DMX_DSR(af[s3], aA1, i3 * 2048);
+        }
+        constexpr int w_lo = st < FM ? st * FN / FM : 0, w_hi = st < FM ? (st + 1) * FN / FM : 0;
         static_for<w_lo, w_hi>([&wf1, aB1](auto J) { constexpr int j = decltype(J)::value; DMX_DSR(wf1[j], aB1, j * 2048); });
-        // issue-order bookkeeping (all constexpr): reads issued through this step and the newest one this step depends on
-        constexpr auto r = [](int t) { return (t + 2 < NS ? 1 : 0) + (t < FM ? (t + 1) * FN / FM - t * FN / FM : 0); };
+      };
+      // issue-order bookkeeping (all constexpr): reads issued through a step and the newest one the step depends on
+      auto wait_step = [](auto ST) {
+        constexpr int st = decltype(ST)::value;
+        constexpr auto r = [](int t) {
+          const int trickle = t < FM ? (t + 1) * FN / FM - t * FN / FM : 0;
+          return (t + 2 < NS ? 1 : 0) + (LAG && t >= LOWN - (DEF - 2) && t < LOWN ? 1 : 0) + trickle;
+        };
         constexpr auto issued_through = [r](int t) { int n = P0; for (int q = 0; q <= t; ++q) n += r(q); return n; };
         constexpr int total = issued_through(st);
         constexpr int pos_af = st == 0 ? FN + 1 : (st == 1 ? FN + 2 : issued_through(st - 3 < 0 ? -1 : st - 3) + 1);
@@ -343,32 +391,60 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
         constexpr int need = pos_af > pos_w ? pos_af : pos_w;
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(total - need) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int kk = st / FM, i = st - kk * FM;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
       };
       // The address arithmetic of tile ks + NSTAGE - 1 runs right behind the prologue fragment reads (under their latency).
       __builtin_amdgcn_sched_barrier(0);
       issue_begin(ks + NSTAGE - 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
-      // the PER LDS-DMA instructions of the step are slipped in behind the MFMA groups of the first SPREAD fragment steps
+      // the PER LDS-DMA instructions of the step are slipped in behind the MFMA groups of SPREAD fragment steps
       constexpr int SPREAD = NS / 2 > 0 ? NS / 2 : 1;
-      static_for<0, NS>([&](auto ST) {
-        constexpr int st = decltype(ST)::value;
-        frag_step(ST);
-        if constexpr (st < SPREAD) {
-          static_for<st * PER / SPREAD, (st + 1) * PER / SPREAD>(issue_one);
+      if constexpr (LAG) {
+        // carried steps of the previous K step (fragments in registers since before the barrier), LDS-DMA issues underneath
+        if (ks > 0) {
+          static_for<LOWN, NS>([&](auto ST) {
+            constexpr int st = decltype(ST)::value;
+            mfma_step(ST);
+            static_for<(st - LOWN) * PER / DEF, (st - LOWN + 1) * PER / DEF>(issue_one);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        } else {
+          static_for<0, PER>(issue_one);
           __builtin_amdgcn_sched_barrier(0);
         }
-      });
-#undef DMX_DSR
+        if constexpr (P0_LATE) { prologue_reads(); __builtin_amdgcn_sched_barrier(0); }
+        static_for<0, LOWN>([&](auto ST) {
+          read_step(ST);
+          wait_step(ST);
+          mfma_step(ST);
+        });
+      } else {
+        static_for<0, NS>([&](auto ST) {
+          constexpr int st = decltype(ST)::value;
+          read_step(ST);
+          wait_step(ST);
+          mfma_step(ST);
+          if constexpr (st < SPREAD) {
+            static_for<st * PER / SPREAD, (st + 1) * PER / SPREAD>(issue_one);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
+      }
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+      nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
     }
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)" ::"n"(KEEP) : "memory");
-    __builtin_amdgcn_s_barrier();
-    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
-    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
+    if constexpr (LAG) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (nk > 0) static_for<LOWN, NS>(mfma_step);     // the last K step's carried steps
+    }
+  };
+  if constexpr (STAGGER) {
+    if (wave >= NW / 2) kloop(std::true_type{}); else kloop(std::false_type{});
+  } else {
+    kloop(std::false_type{});
   }
+#undef DMX_DSR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill tail ...
   __builtin_amdgcn_s_barrier();                          // ... of every wave before the stage buffers are reused by the epilogue
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
@@ -458,7 +534,7 @@ static const TileEntry g_tile_table[] = {
 
 bool glds_ok(const GemmDesc& d) {
   // operand spans must stay below 2 GiB for the 32-bit buffer offsets of the LDS-DMA kernels
-  return (long long)d.M * d.lda < (1ll << 29) && (long long)d.N * d.ldw < (1ll << 29) && d.sy == 1;
+  return (long long)d.M * d.lda < (1ll << 29) && ((long long)d.N + 512) * d.ldw < (1ll << 29) && d.sy == 1;
 }
 int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   g_last_cfg = cfg;
