@@ -19,7 +19,7 @@ namespace {
 
 constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
 #ifndef DMX_DEF_BIG
-#define DMX_DEF_BIG 4      // fragment steps the lagging half of the register-bound 320-row tiles carries across the barrier (0 = no stagger there; 4 is what its 256 registers hold)
+#define DMX_DEF_BIG 0      // fragment steps the lagging half of the register-bound 320-row tile carries across the barrier: 0 = that tile stays unstaggered (measured: 2 or 4 carried steps cost it 2 %, its 256 registers hold no more)
 #endif
 
 
@@ -330,7 +330,11 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // DEF = fragment steps the lagging half carries across the barrier: half a K step where the registers allow it (4 * DEF +
   // 4 * FN carried VGPRs next to the FM * FN * 4 accumulators), DMX_DEF_BIG on the register-bound 320-row tile
   constexpr bool ROOMY = FM * FN * 4 + 4 * FM + 8 * FN + 64 <= 256;
+#ifdef DMX_NO_STAGGER
+  constexpr bool STAGGER = false;
+#else
   constexpr bool STAGGER = NW == 8 && FM >= 2 && (ROOMY || DMX_DEF_BIG > 0);
+#endif
   constexpr int DEF = ROOMY ? FM : (DMX_DEF_BIG > 0 ? (DMX_DEF_BIG < FM ? DMX_DEF_BIG : FM) : 1);
   constexpr int LOWN = NS - DEF;                               // steps of the current K step the lagging half runs before the barrier
   static_assert(DEF <= FM && DEF >= 1, "carried steps must all be kk = 1 steps");
