@@ -52,8 +52,8 @@ class GemmDesc(C.Structure):
                 ("XB", C.c_void_p), ("B2", C.c_void_p), ("ldxb", C.c_int), ("ldb2", C.c_int)]
 
 
-EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV, EPI_MASKBITS, EPI_BITS2 = \
-    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048
+EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV, EPI_MASKBITS, EPI_BITS2, EPI_SOFTBWD = \
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
 
 _SIGS = {
     "dmx_abi_version": (C.c_int, []),
@@ -90,6 +90,7 @@ _SIGS = {
     "dmx_flash_attn_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.c_void_p]),
     "dmx_gemm_splitk_workspace": (C.c_int, [C.c_void_p, C.c_size_t]),
     "dmx_conv_pair_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_conv_pair_group_raw": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_groupnorm_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dmx_groupnorm_raw": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p]),
     "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),

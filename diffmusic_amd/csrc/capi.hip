@@ -114,6 +114,18 @@ int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes,
   return dmx_conv_pair_launch(a, b, ST(stream));
 }
 
+int dmx_conv_pair_group_raw(int n, const void* descs_a, const void* descs_b, size_t desc_bytes, void* stream) {
+  if (desc_bytes != sizeof(GemmDesc)) { dmx_set_error("GemmDesc size mismatch: %zu vs %zu", desc_bytes, sizeof(GemmDesc)); return DMX_ERR_SHAPE; }
+  if (n < 1 || n > 3) { dmx_set_error("conv pair group: 1..3 problems"); return DMX_ERR_SHAPE; }
+  const GemmDesc* a = reinterpret_cast<const GemmDesc*>(descs_a);
+  const GemmDesc* b = reinterpret_cast<const GemmDesc*>(descs_b);
+  const GemmDesc* pa[3]; const GemmDesc* pb[3];
+  for (int j = 0; j < n; ++j) { pa[j] = a + j; pb[j] = b + j; }
+  const int rc = dmx_conv_pair_group_launch(n, pa, pb, ST(stream));
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("shape not handled by the fused convolution-pair kernel");
+  return rc;
+}
+
 int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, const float* colbias, int B, int Nq, int Nk, int Nkp, int C,
                        int heads, float scale, void* stream) {
   const int rc = dmx_flash_attn_fwd((const act_t*)q, (const act_t*)k, (const act_t*)vT, (act_t*)o, colbias, B, Nq, Nk, Nkp, C, heads, scale,

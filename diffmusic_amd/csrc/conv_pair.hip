@@ -81,11 +81,11 @@ __device__ __forceinline__ void pair_settle(PairFrags<2>& f) {
                : "memory");
 }
 
+// one workgroup of the fused pair: `bid` of `nwg` workgroups of the launch (or of this problem's share of a grouped launch)
 template <int C>
-__global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pair_kernel(const PairParams P) {
+__device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int bid, const int nwg) {
   using K = PairCfg<C>;
   constexpr int PITCH = K::PITCH, CPR = K::CPR, FN = K::FN, NS = K::NS, PER = K::PER, TILE = K::TILE, NT = K::NT, NW = K::NW, WN = K::WN;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* ring = smem;                                   // 1 KiB-aligned LDS-DMA targets first
   char* slab = smem + NS * TILE;
   unsigned char* s_bits = reinterpret_cast<unsigned char*>(slab + K::SLAB_BYTES);
@@ -93,9 +93,8 @@ __global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pa
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave / WN, cg = wave - rg * WN;       // row group (64 intermediate rows) and column group (64 channels) of this wave
-  int bid = blockIdx.x;
   {  // XCD-aware remap: neighbouring time tiles (shared halos, same weights) land on the same L2
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int T = P.T;
@@ -326,9 +325,30 @@ __global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pa
     static_assert(EPI_WAVE_BYTES * NW <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
     const int mbase = b * T + t0;
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
-    gemm_epilogue_lds_impl<4, FN, true>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
+    gemm_epilogue_lds_impl<4, FN, 1>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
                                         !single && P.r_from_slab != 0);
   }
+}
+
+template <int C>
+__global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pair_kernel(const PairParams P) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  pair_body<C>(P, smem, blockIdx.x, gridDim.x);
+}
+
+// Grouped launch: up to DMX_PAIR_GROUP independent pairs of the same width (the k = 3 / 7 / 11 branches of one HiFi-GAN resblock
+// step) as ONE grid, problem j = blockIdx.y, longest problem first.  Alone, each branch is ~5 rounds of workgroups over the 256
+// CUs and two of the three end with a nearly empty sixth round (1288 and 1304 workgroups for 1280 slots at C = 128: 16 % of their
+// time); as one grid the short k = 3 workgroups fill the tails of the long ones.  gridDim.x is a multiple of 8 (the surplus
+// workgroups of the shorter problems exit at once), so blockIdx.x & 7 is still the XCD the remap assumes.
+constexpr int DMX_PAIR_GROUP = 3;
+struct PairGroup { PairParams p[DMX_PAIR_GROUP]; int n[DMX_PAIR_GROUP]; };
+template <int C>
+__global__ __launch_bounds__(PairCfg<C>::NT, PairCfg<C>::MIN_WAVES) void conv_pair_group_kernel(const PairGroup G) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int j = blockIdx.y, n = G.n[j];
+  if ((int)blockIdx.x >= n) return;
+  pair_body<C>(G.p[j], smem, blockIdx.x, n);
 }
 
 struct Halo { int lo, hi; bool ok; int d; };
@@ -385,11 +405,9 @@ bool dmx_conv_pair_eligible(const GemmDesc* a, const GemmDesc& b) {
   return true;
 }
 
-// a == nullptr: plain slab convolution of `b`.  Otherwise b.A must be the tensor stage `a` produces
-// (a.C2 when a carries EPI_LRELU2, else a.C); it is taken from LDS and, in the latter case, never written.
-int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
-  if (!dmx_conv_pair_eligible(a, b)) return DMX_ERR_SHAPE;
-  PairParams P;
+namespace {
+// fills the kernel parameters of one pair; returns its workgroup count, FLOPs and algorithmic bytes
+long long pair_params(const GemmDesc* a, const GemmDesc& b, PairParams& P, double& fl, double& by) {
   memset(&P, 0, sizeof(P));
   P.b = b;
   P.single = a ? 0 : 1;
@@ -404,11 +422,9 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   P.r_from_slab = (a && (b.flags & EPI_RESID) && b.R == a->A && b.ldr == b.N) ? 1 : 0;
   P.a_tape_bits_only = (a && (a->flags & EPI_BITS2) && !a->C2) ? 1 : 0;
   const int nclips = b.M / P.T;
-  const long long grid = (long long)nclips * P.nb;
-  if (grid > 0x7fffffffLL) return DMX_ERR_SHAPE;
   const int C = b.N;
-  double fl = 2.0 * b.M * (double)b.N * b.K;
-  double by = 2.0 * b.M * (double)C * 2.0;                     // input + output
+  fl = 2.0 * b.M * (double)b.N * b.K;
+  by = 2.0 * b.M * (double)C * 2.0;                     // input + output
   const double bits_by = b.M * (double)C / 8.0;
   if (a) {
     fl += 2.0 * a->M * (double)a->N * a->K;
@@ -423,6 +439,19 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   if (b.flags & EPI_BITS2) by += bits_by;
   if (b.flags & EPI_ACCUM) by += 2.0 * b.M * (double)C;
   if ((b.flags & EPI_LRELU2) && !(b.flags & EPI_NO_C)) by += 2.0 * b.M * (double)C;
+  return (long long)nclips * P.nb;
+}
+}  // namespace
+
+// a == nullptr: plain slab convolution of `b`.  Otherwise b.A must be the tensor stage `a` produces
+// (a.C2 when a carries EPI_LRELU2, else a.C); it is taken from LDS and, in the latter case, never written.
+int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
+  if (!dmx_conv_pair_eligible(a, b)) return DMX_ERR_SHAPE;
+  PairParams P;
+  double fl, by;
+  const long long grid = pair_params(a, b, P, fl, by);
+  if (grid > 0x7fffffffLL) return DMX_ERR_SHAPE;
+  const int C = b.N;
   const int rec = dmx_prof_open(st);
   auto launch = [&](auto tag) {
     constexpr int CC = decltype(tag)::value;
@@ -434,5 +463,57 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   else if (C == 64) launch(std::integral_constant<int, 64>{});
   else launch(std::integral_constant<int, 128>{});
   dmx_prof_close(rec, st, fl, by, b.M, b.N, (a ? a->K : 0) + b.K, b.ntaps, b.flags, a ? 21 : 20);
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
+// n (<= 3) independent fused pairs of the same width in one grid (see conv_pair_group_kernel).  The pairs must not depend on each
+// other's outputs and must not accumulate into the same tensor.  Falls back to n launches when the shapes differ in width.
+int dmx_conv_pair_group_launch(int n, const GemmDesc* const* a, const GemmDesc* const* b, hipStream_t st) {
+  if (n < 1 || n > DMX_PAIR_GROUP) return DMX_ERR_SHAPE;
+  static const bool off = getenv("DMX_NO_PAIR_GROUP") != nullptr;
+  bool same = !off && n > 1;
+  for (int j = 0; j < n; ++j) {
+    if (!a[j] || !b[j] || !dmx_conv_pair_eligible(a[j], *b[j])) return DMX_ERR_SHAPE;
+    if (b[j]->N != b[0]->N) same = false;
+    for (int i = 0; i < j; ++i)                               // no two problems may write the same tensor
+      if (b[j]->C == b[i]->C || (b[j]->C2 && b[j]->C2 == b[i]->C2)) same = false;
+  }
+  if (!same) {
+    for (int j = 0; j < n; ++j) { const int rc = dmx_conv_pair_launch(a[j], *b[j], st); if (rc != DMX_OK) return rc; }
+    return DMX_OK;
+  }
+  // longest problem first: order by K steps per workgroup (stage A + stage B)
+  int order[DMX_PAIR_GROUP] = {0, 1, 2};
+  auto work = [&](int j) { return a[j]->K + b[j]->K; };
+  for (int i = 0; i < n; ++i)
+    for (int k = i + 1; k < n; ++k)
+      if (work(order[k]) > work(order[i])) { const int t = order[i]; order[i] = order[k]; order[k] = t; }
+  PairGroup G;
+  memset(&G, 0, sizeof(G));
+  double fl = 0.0, by = 0.0;
+  long long gmax = 0;
+  int Ksum = 0;
+  for (int i = 0; i < n; ++i) {
+    const int j = order[i];
+    double f1, b1;
+    const long long g = pair_params(a[j], *b[j], G.p[i], f1, b1);
+    if (g > 0x7ffffff0LL) return DMX_ERR_SHAPE;
+    G.n[i] = (int)g;
+    if (g > gmax) gmax = g;
+    fl += f1; by += b1; Ksum += a[j]->K + b[j]->K;
+  }
+  const unsigned gx = (unsigned)((gmax + 7) & ~7ll);
+  const int C = b[0]->N;
+  const int rec = dmx_prof_open(st);
+  auto launch = [&](auto tag) {
+    constexpr int CC = decltype(tag)::value;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_pair_group_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<CC>::LDS_BYTES); attr = true; }
+    hipLaunchKernelGGL(conv_pair_group_kernel<CC>, dim3(gx, (unsigned)n), dim3(PairCfg<CC>::NT), PairCfg<CC>::LDS_BYTES, st, G);
+  };
+  if (C == 32) launch(std::integral_constant<int, 32>{});
+  else if (C == 64) launch(std::integral_constant<int, 64>{});
+  else launch(std::integral_constant<int, 128>{});
+  dmx_prof_close(rec, st, fl, by, b[0]->M, C, Ksum, b[0]->ntaps, b[0]->flags, 22);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }

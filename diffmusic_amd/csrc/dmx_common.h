@@ -89,8 +89,10 @@ enum {
   EPI_NO_C = 256,      // skip the primary output (only C2)
   EPI_RESID_INV = 512, // R holds leaky_relu(x, 1/resid_inv_slope): the residual added is the reconstructed x
   EPI_MASKBITS = 1024, // like EPI_MASK, but the mask source is a SIGN-BIT tensor XB: byte [row][n / 8], bit (n & 7) set <=> x > 0
-  EPI_BITS2 = 2048     // also write the sign bits (v > 0) of the stored value to B2 (same layout): the leaky-relu' mask of the
+  EPI_BITS2 = 2048,    // also write the sign bits (v > 0) of the stored value to B2 (same layout): the leaky-relu' mask of the
                        // backward sweep at 1/16 of the bytes of the 16-bit tensor (HiFi-GAN tape)
+  EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
+                       // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };
 
 struct GemmDesc {

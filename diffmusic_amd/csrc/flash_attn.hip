@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
     const int key0 = blk * FA_KB;
     const float c = P.c;
     const bool tail = key0 + FA_KB > Nk;
-    if (P.colbias || tail) {
+    // generic blocks (bias or key tail) scale the logits here; full unbiased blocks keep them raw and fold the scale into the one
+    // FMA in front of the exponential (c > 0: max(c * s) = c * max(s)) -- 32 multiplies fewer per block in a VALU-bound loop
+    const bool raw = !(P.colbias || tail);
+    if (!raw) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int kbase = key0 + t * 16 + lq * 4;
@@ -153,42 +156,37 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[t][qt][e] = (kbase + e < Nk) ? __builtin_fmaf(s[t][qt][e], c, bb[e]) : NEG;
       }
-    } else {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) s[t][qt][e] *= c;
     }
-    // ---- online softmax per query (= per lane column); the four lanes of a query share the maximum
+    const float cs = raw ? c : 1.f;                    // what is still to be applied to the stored logits
+    // ---- online softmax per query (= per lane column); the four lanes of a query share the maximum.  The arithmetic runs on
+    // 4-vectors so that the compiler can use the packed fp32 forms (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
     frag8_t pf[2][2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = NEG;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) mx = fmaxf(mx, s[t][qt][e]);
+      float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                       fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+      mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][qt][0], s[2][qt][1]), fmaxf(s[2][qt][2], s[2][qt][3])),
+                           fmaxf(fmaxf(s[3][qt][0], s[3][qt][1]), fmaxf(s[3][qt][2], s[3][qt][3]))));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run[qt], mx);
+      const float m_new = fmaxf(m_run[qt], mx * cs);
       const float alpha = __builtin_amdgcn_exp2f(m_run[qt] - m_new);     // first block: exp2(-inf) = 0
       m_run[qt] = m_new;
-      float sum = 0.f;
+      const f32x4 c4 = f32x4{cs, cs, cs, cs}, nm4 = f32x4{-m_new, -m_new, -m_new, -m_new};
+      f32x4 sum4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 v = s[t][qt] * c4 + nm4;                              // masked keys: -inf * 1 - m = -inf -> p = 0
+        f32x4 pv;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f(s[t][qt][e] - m_new);
-          s[t][qt][e] = p;
-          sum += p;
-        }
-      l_run[qt] = l_run[qt] * alpha + sum;
+        for (int e = 0; e < 4; ++e) pv[e] = __builtin_amdgcn_exp2f(v[e]);
+        s[t][qt] = pv;
+        sum4 += pv;
+      }
+      l_run[qt] = l_run[qt] * alpha + ((sum4[0] + sum4[1]) + (sum4[2] + sum4[3]));
+      const f32x4 al4 = f32x4{alpha, alpha, alpha, alpha};
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) oacc[dt][qt][e] *= alpha;
+      for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= al4;
       // P^T fragments: k slots (lq, j) of MFMA step kk <-> keys 32kk + {4lq + j, 16 + 4lq + j}
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {

@@ -23,7 +23,7 @@ constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
 #endif
 
 
-template <int BM, int BN, int WM, int WN, bool BITS>
+template <int BM, int BN, int WM, int WN, int EM>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN, BITS>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, EM>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
 }
 
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 // range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
 constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int EM>
 __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
@@ -457,7 +457,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN, BITS>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, EM>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
 }
 
@@ -468,54 +468,59 @@ __device__ __forceinline__ int xcd_remap(int bid) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int EM>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x);
-  glds_tile<BM, BN, WM, WN, NSTAGE, BITS>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
+  glds_tile<BM, BN, WM, WN, NSTAGE, EM>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, bool BITS>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int EM>
 int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int SMEM = NSTAGE * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, BITS>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, EM>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
-  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, BITS>), grid, dim3(NT), SMEM, stream, d);
+  hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, EM>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 // the sign-bit tape epilogue (HiFi-GAN layers) is a separate instantiation of every tile
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_glds(const GemmDesc& d, hipStream_t stream) {
-  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_glds_t<BM, BN, WM, WN, NSTAGE, true>(d, stream)
-                                                : launch_glds_t<BM, BN, WM, WN, NSTAGE, false>(d, stream);
+  if (d.flags & EPI_SOFTBWD) {      // the fused softmax backward exists for the tile its one caller (VAE mid attention, N x N scores) gets
+    if constexpr (BM == 256 && BN == 256) return launch_glds_t<BM, BN, WM, WN, NSTAGE, 2>(d, stream);
+    else return DMX_ERR_SHAPE;
+  }
+  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_glds_t<BM, BN, WM, WN, NSTAGE, 1>(d, stream)
+                                                : launch_glds_t<BM, BN, WM, WN, NSTAGE, 0>(d, stream);
 }
 
-template <int BM, int BN, int WM, int WN, bool BITS>
+template <int BM, int BN, int WM, int WN, int EM>
 int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
   constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, BITS>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, EM>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, BITS>), grid, dim3(NT), SMEM, stream, d);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, EM>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmDesc& d, hipStream_t stream) {
-  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_cfg_t<BM, BN, WM, WN, true>(d, stream) : launch_cfg_t<BM, BN, WM, WN, false>(d, stream);
+  if (d.flags & EPI_SOFTBWD) return DMX_ERR_SHAPE;
+  return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_cfg_t<BM, BN, WM, WN, 1>(d, stream) : launch_cfg_t<BM, BN, WM, WN, 0>(d, stream);
 }
 
 }  // namespace
@@ -567,6 +572,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
   const bool gl = !legacy && glds_ok(d);
+  if (d.flags & EPI_SOFTBWD) return gl ? launch_by_cfg(1, d, stream) : DMX_ERR_SHAPE;
   if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
     static int ovN[8], ovC[8], nov = -1;
@@ -719,7 +725,7 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
 int splitk_plan(const GemmDesc& d, int* tile) {
   static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
   if (off || !g_splitk_ws || d.Z != 1 || !glds_ok(d)) return 1;
-  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2)) return 1;
+  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD)) return 1;
   if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
   if ((d.N & 7) || (d.ldc & 3)) return 1;
   const int nk = (d.K + BK - 1) / BK;
@@ -791,6 +797,11 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   // the LDS epilogue evaluates leaky-relu as max(v, v*slope) and the inverse as min(x, x/slope)
   if ((d.flags & EPI_LRELU2) && !(d.act_slope >= 0.f && d.act_slope <= 1.f)) return DMX_ERR_SHAPE;
   if ((d.flags & EPI_RESID_INV) && !(d.resid_inv_slope >= 1.f)) return DMX_ERR_SHAPE;
+  if (d.flags & EPI_SOFTBWD) {
+    // fused softmax backward: 16-bit output through the LDS-staged epilogue, P tile as X, per-row delta in rowbias, Zi == 1
+    if ((d.flags & ~(EPI_SOFTBWD)) || ((d.N | d.ldc | d.ldx) & 7) || !d.X || !d.rowbias || d.Zi != 1 || d.ntaps != 1) return DMX_ERR_SHAPE;
+    if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return DMX_ERR_SHAPE;
+  }
   if (d.flags & (EPI_MASKBITS | EPI_BITS2)) {
     // sign-bit tensors are handled by the LDS-staged epilogue only: 16-bit output, 16-byte granular rows, one batch
     if ((d.flags & EPI_F32OUT) || ((d.N | d.ldc | d.ldr | d.ldx | d.ldc2) & 7) || d.Z != 1) return DMX_ERR_SHAPE;
@@ -810,7 +821,7 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
     if (!(d.flags & EPI_NO_C)) by += mn * ((d.flags & EPI_F32OUT) ? 4.0 : 2.0);
     if (d.flags & EPI_ACCUM) by += mn * ((d.flags & EPI_F32OUT) ? 4.0 : 2.0);
     if (d.flags & (EPI_RESID | EPI_RESID_INV)) by += mn * 2.0;
-    if (d.flags & EPI_MASK) by += mn * 2.0;
+    if (d.flags & (EPI_MASK | EPI_SOFTBWD)) by += mn * 2.0;
     if (d.flags & EPI_MASKBITS) by += mn / 8.0;
     if (d.flags & EPI_BITS2) by += mn / 8.0;
     if (d.C2 && (d.flags & EPI_LRELU2)) by += mn * 2.0;

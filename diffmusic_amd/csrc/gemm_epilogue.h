@@ -112,12 +112,14 @@ struct EpiChunk { static constexpr int IB = (FM % DMX_EPI_IB == 0) ? DMX_EPI_IB 
 // BITS: instantiate the sign-bit tape paths (EPI_MASKBITS / EPI_BITS2).  They live in SEPARATE kernel instantiations (the launcher
 // picks by flag): merely having them in the common epilogue cost every other layer ~5 % (measured on the VAE), executed or not,
 // and two copies inside one kernel pushed the 256x256 tile into scratch.
-template <int FM, int FN, bool BITS>
+template <int FM, int FN, int EM>
 __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
                                                        long long coff, int HqWq, char* wl, int mlimit,
                                                        const uint2 (&rpre)[FM * FN], const bool use_rpre) {
   // rpre: the residual tile already in registers in accumulator layout ([FM][FN] 8-byte pieces; conv_pair.hip takes it from
   // its LDS slab) -- the residual tensor is then not read from HBM again
+  constexpr bool BITS = EM == 1;          // sign-bit tape paths
+  constexpr bool SOFT = EM == 2;          // fused softmax backward (EPI_SOFTBWD)
   constexpr int CH = EpiChunk<FM>::CH;
   constexpr int IB = EpiChunk<FM>::IB;
   constexpr int TNB = FN * 32;            // bytes per tile row
@@ -266,6 +268,17 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           a[0] *= (nib & 1u) ? 1.f : sl; a[1] *= (nib & 2u) ? 1.f : sl; a[2] *= (nib & 4u) ? 1.f : sl; a[3] *= (nib & 8u) ? 1.f : sl;
         }
       }
+    } else if (SOFT && (flags & EPI_SOFTBWD)) {
+      // dS = P * (dP - delta[row]): delta is one fp32 per GEMM row of this batch (coff = z * sCo since Zi == 1)
+      const float* rv = p.rowbias + (p.sCo ? coff / p.sCo : 0ll) * (long long)p.M;
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const int m = m0 + h * CH + ii * 16 + lr;
+        const float dl = m < mend ? rv[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] -= dl; a[1] -= dl; a[2] -= dl; a[3] -= dl; }
+      }
+      stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) { a[0] *= x0; a[1] *= x1; a[2] *= x2; a[3] *= x3; });
     } else if (flags & EPI_MASK) {
       const float sl = p.mask_slope;
       stage_in(p.X, p.ldx, [&](f32x4& a, float x0, float x1, float x2, float x3) {
@@ -348,11 +361,11 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
 #undef DMX_LDS_SYNC
 }
 
-template <int FM, int FN, bool BITS>
+template <int FM, int FN, int EM>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmDesc& p, f32x4 (&acc)[FM][FN], int m0, int n0, int lane,
                                                   long long coff, int HqWq, char* wl, int mlimit = 0x7fffffff) {
   const uint2 none[FM * FN] = {};
-  gemm_epilogue_lds_impl<FM, FN, BITS>(p, acc, m0, n0, lane, coff, HqWq, wl, mlimit, none, false);
+  gemm_epilogue_lds_impl<FM, FN, EM>(p, acc, m0, n0, lane, coff, HqWq, wl, mlimit, none, false);
 }
 
 }  // namespace

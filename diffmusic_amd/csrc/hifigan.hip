@@ -175,6 +175,43 @@ struct HifiGan : Model {
       }
       const float next_slope = (s == ns - 1) ? 0.01f : slope;
       const bool mt = multi();
+      bool all_fused = nk <= 3;
+      for (int k = 0; k < nk; ++k) for (int d = 0; d < nd; ++d) all_fused = all_fused && fused[idx(s, k, d)] != 0;
+      if (all_fused && !mt) {
+        // narrow stage, every resblock step in the fused pair kernel: step d of all nk branches is ONE grouped launch (the branches
+        // are independent until the averaged sum); the last step accumulates into `sum` in branch order and stays nk launches
+        for (int d = 0; d < nd; ++d) {
+          GemmDesc da[DMX_MAX_STAGES], db[DMX_MAX_STAGES];
+          const GemmDesc* pa[DMX_MAX_STAGES]; const GemmDesc* pb[DMX_MAX_STAGES];
+          for (int k = 0; k < nk; ++k) {
+            const int id = idx(s, k, d);
+            {
+              Epi e; e.flags = EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.act_slope = slope; e.B2 = hb[id];
+              RUN(conv_fwd_1d_desc(c1[id], xa[id], ha[id], B, To, e, da[k]));
+            }
+            if (d < nd - 1) {
+              const int idn = idx(s, k, d + 1);
+              act_t* xn = xa[idn];
+              Epi e; e.flags = EPI_RESID | EPI_RESID_INV | EPI_LRELU2 | EPI_NO_C | EPI_BITS2; e.R = xa[id]; e.resid_inv_slope = 1.f / slope;
+              e.act_slope = slope; e.C2 = xn; e.B2 = xb[idn];
+              RUN(conv_fwd_1d_desc(c2[id], ha[id], xn, B, To, e, db[k]));
+            } else {
+              Epi e; e.flags = EPI_RESID | EPI_RESID_INV; e.R = xa[id]; e.resid_inv_slope = 1.f / slope; e.alpha = 1.f / nk;
+              if (k > 0) e.flags |= EPI_ACCUM;
+              if (k == nk - 1) { e.flags |= EPI_LRELU2 | EPI_NO_C; e.act_slope = next_slope; e.C2 = act_out[s]; }
+              RUN(conv_fwd_1d_desc(c2[id], ha[id], sum, B, To, e, db[k]));
+            }
+            pa[k] = &da[k]; pb[k] = &db[k];
+          }
+          if (dry) continue;
+          if (d < nd - 1) RUN(dmx_conv_pair_group_launch(nk, pa, pb, st));
+          else for (int k = 0; k < nk; ++k) RUN(conv_pair_run(da[k], db[k], st));
+        }
+        arena.release(mk);
+        cur_act = act_out[s];
+        Tin = To;
+        continue;
+      }
       hipEvent_t fin_prev = nullptr;
       if (mt) {
         hipEvent_t e0 = next_event();
@@ -261,6 +298,35 @@ struct HifiGan : Model {
       CHECK_WS("hifigan");
       const bool mt = multi();
       hipEvent_t fin_prev = nullptr;
+      bool all_fused = nk <= 3;
+      for (int k = 0; k < nk; ++k) for (int d = 0; d < nd; ++d) all_fused = all_fused && fused[idx(s, k, d)] != 0;
+      if (all_fused && !mt) {
+        // grouped launches as in forward(): step d of all branches at once; the last step (d = 0) accumulates into gxs in branch order
+        const act_t* gcs[DMX_MAX_STAGES];
+        for (int k = 0; k < nk; ++k) gcs[k] = g;
+        for (int d = nd - 1; d >= 0; --d) {
+          GemmDesc da[DMX_MAX_STAGES], db[DMX_MAX_STAGES];
+          const GemmDesc* pa[DMX_MAX_STAGES]; const GemmDesc* pb[DMX_MAX_STAGES];
+          act_t* dsts[DMX_MAX_STAGES];
+          for (int k = 0; k < nk; ++k) {
+            const int id = idx(s, k, d);
+            {
+              Epi e; e.mask_slope = slope; e.flags = EPI_MASKBITS; e.XB = hb[id];
+              RUN(conv_bwd_1d_desc(c2[id], gcs[k], ghk[k], B, To, e, da[k]));
+            }
+            Epi e; e.flags = EPI_RESID | EPI_MASKBITS; e.mask_slope = slope; e.R = gcs[k]; e.XB = xb[id];
+            if (d == 0) { dsts[k] = gxs; if (k > 0) e.flags |= EPI_ACCUM; }
+            else dsts[k] = (gcs[k] == gAB[k][0]) ? gAB[k][1] : gAB[k][0];
+            RUN(conv_bwd_1d_desc(c1[id], ghk[k], dsts[k], B, To, e, db[k]));
+            pa[k] = &da[k]; pb[k] = &db[k];
+          }
+          if (!dry) {
+            if (d > 0) RUN(dmx_conv_pair_group_launch(nk, pa, pb, st));
+            else for (int k = 0; k < nk; ++k) RUN(conv_pair_run(da[k], db[k], st));
+          }
+          for (int k = 0; k < nk; ++k) gcs[k] = dsts[k];
+        }
+      } else {
       if (mt) {
         hipEvent_t e0 = next_event();
         (void)hipEventRecord(e0, st);
@@ -292,6 +358,7 @@ struct HifiGan : Model {
           if (d == 0 && mt) { fin_prev = next_event(); (void)hipEventRecord(fin_prev, sk); }
           gc = dst;
         }
+      }
       }
       if (mt && fin_prev) (void)hipStreamWaitEvent(st, fin_prev, 0);
       // through the upsampler (strided conv) and the leaky-relu that fed it

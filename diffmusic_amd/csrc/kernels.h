@@ -19,6 +19,7 @@ int dmx_softmax_act(const act_t* S, act_t* P, const float* colbias, long long ro
                     hipStream_t st);
 int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,
                     hipStream_t st);
+int dmx_rowdot(const act_t* a, const act_t* b, float* out, long long rows, int C, long long lda, long long ldb, hipStream_t st);
 int dmx_geglu(const act_t* x, act_t* y, long long rows, int I, hipStream_t st);
 int dmx_silu(const act_t* x, act_t* y, long long n, hipStream_t st);
 int dmx_upsample_nearest(const act_t* x, act_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, hipStream_t st);

@@ -23,7 +23,7 @@ struct VaeDecoder : Model {
   std::vector<std::vector<ResnetTape>> t_up;
   GnTape t_attn_gn, t_norm_out;
   const act_t* attn_x = nullptr;
-  act_t *aq = nullptr, *ak = nullptr, *av = nullptr, *aP = nullptr;
+  act_t *aq = nullptr, *ak = nullptr, *av = nullptr, *aP = nullptr, *ao = nullptr;   // q, k, v, probabilities, attention output
   const act_t* final_x = nullptr;
 
   explicit VaeDecoder(const dmx_vae_config& c) : cfg(c) {
@@ -104,10 +104,11 @@ struct VaeDecoder : Model {
       t_attn_gn = attn_gn.alloc(cx, B);
       aq = A.bf((size_t)B * N * C); ak = A.bf((size_t)B * N * C); av = A.bf((size_t)B * N * C);
       aP = keep ? A.bf((size_t)B * N * pad8(N)) : nullptr;
+      ao = keep ? A.bf((size_t)B * N * C) : nullptr;      // O = P V stays on the tape: delta = rowsum(dO * O) in the backward pass
       act_t* out = A.bf((size_t)B * N * C);
       const size_t mk = A.mark();
       act_t* xn = A.bf((size_t)B * N * C);
-      act_t* o = A.bf((size_t)B * N * C);
+      act_t* o = keep ? ao : A.bf((size_t)B * N * C);
       CTRY(attn_gn.fwd(cx, x, xn, B, N, 0, t_attn_gn));
       Epi e;
       CRUN(linear_fwd(to_q, xn, C, aq, C, (long long)B * N, e, st));
@@ -208,7 +209,7 @@ struct VaeDecoder : Model {
       act_t* go = A.bf((size_t)B * N * C);
       act_t* goT = A.bf((size_t)B * N * C);
       act_t* PT = A.bf((size_t)B * N * N);
-      float* dP = A.f32((size_t)B * N * N);
+      float* delta = A.f32((size_t)B * N);
       act_t* dS = A.bf((size_t)B * N * N);
       act_t* T1 = A.bf((size_t)B * N * C);
       act_t* gq = A.bf((size_t)B * N * C);
@@ -217,17 +218,19 @@ struct VaeDecoder : Model {
       act_t* gxn = A.bf((size_t)B * N * C);
       CRUN(linear_bwd(to_out, g, C, go, C, (long long)B * N, e, st));
       GemmBatch gb; gb.Z = B; gb.Zi = 1;
-      // dP = go . v^T   (B, N, N) fp32
+      // dS = P * (go . v^T - delta) * scale with delta = rowsum(go * O) (= rowsum(dP * P)): the softmax backward runs in the
+      // epilogue of the dP GEMM, so neither the fp32 dP (512 MB at B = 8) nor a separate softmax-backward pass exists
+      CRUN(dmx_rowdot(go, ao, delta, (long long)B * N, C, C, C, st));
       gb.sAo = (long long)N * C; gb.sBo = (long long)N * C; gb.sCo = (long long)N * N;
-      Epi ef; ef.flags = EPI_F32OUT;
-      CRUN(gemm_nt(go, C, av, C, dP, N, N, N, C, ef, gb, st));
+      {
+        Epi es; es.flags = EPI_SOFTBWD; es.X = aP; es.rowbias = delta; es.alpha = scale;
+        CRUN(gemm_nt(go, C, av, C, dS, N, N, N, C, es, gb, st));
+      }
       // dv = P^T . go = gemm_nt(PT (Nk,Nq), goT (C,Nq))
       CRUN(dmx_transpose(aP, PT, N, N, N, N, B, 1, (long long)N * N, 0, (long long)N * N, 0, st));
       CRUN(dmx_transpose(go, goT, N, C, C, N, B, 1, (long long)N * C, 0, (long long)N * C, 0, st));
       gb.sAo = (long long)N * N; gb.sBo = (long long)N * C; gb.sCo = (long long)N * C;
       CRUN(gemm_nt(PT, N, goT, N, gv, C, N, C, N, e, gb, st));
-      // dS = P * (dP - rowsum(dP*P)) * scale
-      CRUN(dmx_softmax_bwd(aP, dP, dS, (long long)B * N, N, N, scale, st));
       // dq = dS . k = gemm_nt(dS (Nq,Nk), kT (C,Nk))
       CRUN(dmx_transpose(ak, T1, N, C, C, N, B, 1, (long long)N * C, 0, (long long)N * C, 0, st));
       CRUN(gemm_nt(dS, N, T1, N, gq, C, N, C, N, e, gb, st));

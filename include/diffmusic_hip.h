@@ -206,6 +206,9 @@ int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, co
  * installs its own */
 int dmx_gemm_splitk_workspace(void* ws, size_t bytes);
 int dmx_conv_pair_raw(const void* desc_a, const void* desc_b, size_t desc_bytes, void* stream);
+/* test hook: n (<= 3) mutually independent fused pairs of one width as ONE grid, longest problem first (the k = 3 / 7 / 11 branches
+ * of a HiFi-GAN resblock step, transformers HifiGanResidualBlock.forward); descs_a / descs_b: n consecutive descriptors each. */
+int dmx_conv_pair_group_raw(int n, const void* descs_a, const void* descs_b, size_t desc_bytes, void* stream);
 /* test hook: GroupNorm (+ SiLU) forward as the U-Net / VAE executors run it (diffusers ResnetBlock2D norm1 / norm2, Attention
  * group_norm; reached from pipeline_musicldm.py:696-703 and scheduling_dps.py:195-197).  x, y (B, P, C) fp16 channels-last;
  * stats (B, G, 2) = (mean, rstd), scale / shift (B, C) fp32 outputs; partial: fp32 scratch of dmx_groupnorm_scratch_floats(B, C, G). */

@@ -260,6 +260,69 @@ def test_split_k_small_m_conv(B, H, W, Ci, Co):
     assert _rel(outs[1], outs[0]) < 2e-3
 
 
+@pytest.mark.parametrize("B,T,Cc", [(2, 3000, 32), (2, 2500, 64), (1, 3001, 128)])
+def test_grouped_pair_launch_is_bitwise_the_separate_launches(B, T, Cc):
+    """The k = 3 / 7 / 11 branches of one resblock step as ONE grid (dmx_conv_pair_group_raw) give bit for bit what three fused
+    launches give: the grouping only changes which workgroup runs where."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(21)
+    slope = 0.1
+    ks, dil = (3, 7, 11), 3
+    xa = F.leaky_relu(torch.randn(B, T, Cc, generator=g), slope).to(_adt()).cuda()
+    res = {}
+    for mode in ("group", "single"):
+        das, dbs, keep = (L.GemmDesc * 3)(), (L.GemmDesc * 3)(), []
+        outs = []
+        for j, k in enumerate(ks):
+            gj = torch.Generator().manual_seed(100 + k)
+            w1 = (torch.randn(Cc, Cc, k, generator=gj) / (Cc * k) ** 0.5).to(_adt()).cuda()
+            w2 = (torch.randn(Cc, Cc, k, generator=gj) / (Cc * k) ** 0.5).to(_adt()).cuda()
+            b1, b2 = torch.randn(Cc, generator=gj).cuda() * 0.1, torch.randn(Cc, generator=gj).cuda() * 0.1
+            w1p = w1.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+            w2p = w2.permute(0, 2, 1).reshape(Cc, k * Cc).contiguous()
+            ha = torch.zeros(B, T, Cc, dtype=_adt(), device="cuda")
+            xn = torch.zeros_like(ha)
+            raw = torch.zeros_like(ha)
+            das[j] = _conv_desc(L, xa, w1p, k, dil, Cc, B, T, C=ha, C2=ha, bias=b1, flags=L.EPI_BIAS | L.EPI_LRELU2 | L.EPI_NO_C, act_slope=slope)
+            dbs[j] = _conv_desc(L, ha, w2p, k, 1, Cc, B, T, C=raw, C2=xn, bias=b2, R=xa, resid_inv_slope=1.0 / slope, act_slope=slope,
+                                flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_RESID_INV | L.EPI_LRELU2)
+            keep += [w1p, w2p, b1, b2]
+            outs += [ha, raw, xn]
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if mode == "group":
+            L.check(L.lib().dmx_conv_pair_group_raw(3, C.byref(das), C.byref(dbs), C.sizeof(L.GemmDesc), st), "pair group")
+        else:
+            for j in range(3):
+                _pair_run(L, das[j], dbs[j])
+        torch.cuda.synchronize()
+        res[mode] = outs
+    for a, b in zip(res["group"], res["single"]):
+        assert torch.equal(a, b)
+    assert res["group"][1].float().abs().max().item() > 0.1
+
+
+@pytest.mark.parametrize("Z,N,Cc", [(2, 520, 64), (1, 1000, 512), (3, 264, 128)])
+def test_softmax_backward_fused_into_the_dp_gemm(Z, N, Cc):
+    """EPI_SOFTBWD: dS = P * (dO V^T - delta) * scale with delta = rowsum(dO * O), the attention backward of the VAE mid block
+    (diffusers Attention, single head) without a materialised dP; against torch fp32 on the same fp16-rounded operands."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(31)
+    scale = Cc ** -0.5
+    q = torch.randn(Z, N, Cc, generator=g); kk = torch.randn(Z, N, Cc, generator=g)
+    v = torch.randn(Z, N, Cc, generator=g).to(_adt()).cuda()
+    go = torch.randn(Z, N, Cc, generator=g).to(_adt()).cuda()
+    Pm = torch.softmax(q @ kk.transpose(1, 2) * scale, dim=-1).to(_adt()).cuda().contiguous()
+    O = (Pm.float() @ v.float())
+    delta = (go.float() * O).sum(-1).contiguous()                        # (Z, N) fp32
+    dS = torch.empty(Z, N, N, dtype=_adt(), device="cuda")
+    d = _desc(L, A=go, W=v, C=dS, X=Pm, rowbias=delta, M=N, N=N, K=Cc, ldw=Cc, Hi=1, Wi=N, Ci=Cc, lda=Cc, Hq=1, Wq=N, ntaps=1, Ho=1, Wo=N,
+              ldc=N, ldr=N, ldx=N, ldc2=N, Z=Z, Zi=1, sAo=N * Cc, sWo=N * Cc, sCo=N * N, tdy=[0], tdx=[0], flags=L.EPI_SOFTBWD, alpha=scale)
+    _run(L, d)
+    dP = go.float() @ v.float().transpose(1, 2)
+    ref = Pm.float() * (dP - delta[..., None]) * scale
+    assert _rel(dS, ref) < 4e-3
+
+
 @pytest.mark.parametrize("plan", [212, 313, 414, 611, 815, 318, 202])
 def test_forced_split_k_plans_agree(plan):
     """tile_cfg = 100 * slices + tile forces a split-K plan (what the measured table stores): every plan gives the single-pass result"""
