@@ -18,9 +18,9 @@
 namespace {
 
 constexpr int BK = 64;  // 16-bit elements per K-step (128 B per tile row)
-#ifndef DMX_DEF_BIG
-#define DMX_DEF_BIG 0      // fragment steps the lagging half of the register-bound 320-row tile carries across the barrier: 0 = that tile stays unstaggered (measured: 2 or 4 carried steps cost it 2 %, its 256 registers hold no more)
-#endif
+// fragment steps the lagging half of the register-bound 320-row tile carries across the barrier: 0 = that tile stays unstaggered
+// (measured on one device: 2 or 4 carried steps cost it 2 %; its 256 registers hold no more than 4)
+constexpr int DMX_DEF_BIG = 0;
 
 
 template <int BM, int BN, int WM, int WN, int EM>
@@ -330,11 +330,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // DEF = fragment steps the lagging half carries across the barrier: half a K step where the registers allow it (4 * DEF +
   // 4 * FN carried VGPRs next to the FM * FN * 4 accumulators), DMX_DEF_BIG on the register-bound 320-row tile
   constexpr bool ROOMY = FM * FN * 4 + 4 * FM + 8 * FN + 64 <= 256;
-#ifdef DMX_NO_STAGGER
-  constexpr bool STAGGER = false;
-#else
   constexpr bool STAGGER = NW == 8 && FM >= 2 && (ROOMY || DMX_DEF_BIG > 0);
-#endif
   constexpr int DEF = ROOMY ? FM : (DMX_DEF_BIG > 0 ? (DMX_DEF_BIG < FM ? DMX_DEF_BIG : FM) : 1);
   constexpr int LOWN = NS - DEF;                               // steps of the current K step the lagging half runs before the barrier
   static_assert(DEF <= FM && DEF >= 1, "carried steps must all be kk = 1 steps");
@@ -401,7 +397,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       issue_begin(ks + NSTAGE - 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
       // the PER LDS-DMA instructions of the step are slipped in behind the MFMA groups of SPREAD fragment steps
-      constexpr int SPREAD = NS / 2 > 0 ? NS / 2 : 1;
+      constexpr int SPREAD = NS / 2 > 0 ? NS / 2 : 1;      // (all at the top of the step, or over 3 steps: 5 % slower on the 320-row tile)
       if constexpr (LAG) {
         // carried steps of the previous K step (fragments in registers since before the barrier), LDS-DMA issues underneath
         if (ks > 0) {
