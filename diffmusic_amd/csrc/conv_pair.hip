@@ -48,7 +48,7 @@ struct PairCfg {
   static constexpr int SLAB_ROWS = PAIR_ROWS + PAIR_HALO;
   static constexpr int SLAB_BYTES = SLAB_ROWS * PITCH;
   static constexpr int TILE = C * 128;             // weights of one K step: C rows x 64 k, 128-byte rows, XOR-swizzled chunks
-  static constexpr int NS = 3;
+  static constexpr int NS = C == 128 ? 4 : 3;      // weight ring slots (C = 128: four, one barrier per TWO K steps; see run_stage)
   static constexpr int PER = TILE / 1024 / NW;     // LDS-DMA instructions per wave per K step
   static constexpr int SLAB_IT = (SLAB_ROWS * CPR + NT - 1) / NT;
   static constexpr int BITS_IT = PAIR_ROWS * CPR / NT;
@@ -245,9 +245,47 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
     // fragments out of it first.  (Inside the loop the end-of-step barrier gives this guarantee; without this one ~2 % of the
     // outputs changed from run to run.)
     __builtin_amdgcn_s_barrier();
-    for (int sidx = 0; sidx < n; sidx += 2) {
-      step(fa, fb, isB, sidx, n, g0 + sidx);
-      if (sidx + 1 < n) step(fb, fa, isB, sidx + 1, n, g0 + sidx + 1);
+    if constexpr (C == 128) {
+      // C = 128 (one 8-wave workgroup per CU): K steps run in PAIRS with one barrier per pair.  The ring has four slots: while a pair
+      // (g, g + 1) reads the fragments of tiles g + 1 and g + 2, the weights of tiles g + 3 and g + 4 are fetched into the slots of
+      // tiles g - 1 and g (both fully read before the barrier that started the pair); both fetches go out in the FIRST step of the pair
+      // and must have landed at the barrier that ends it (vmcnt(0): more than a whole K step of latency cover).  Half the barriers,
+      // half the all-waves-wait points of the one-barrier-per-step schedule the narrower instances keep.
+      int sidx = 0;
+      for (; sidx + 1 < n; sidx += 2) {
+        const int g = g0 + sidx;
+        load_frags(fb, isB, sidx + 1, g + 1);
+        mfma_half(fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(g + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(g + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        pair_settle(fb);
+        const bool more = sidx + 2 < n;
+        if (more) load_frags(fa, isB, sidx + 2, g + 2);
+        mfma_half(fb, 0);
+        mfma_half(fb, 1);
+        if (more) pair_settle(fa);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // tiles g + 3 and g + 4 have landed
+        __builtin_amdgcn_s_barrier();
+      }
+      if (sidx < n) {                                                    // odd tail: a single step, its one fetch awaited in full
+        mfma_half(fa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue_dma(g0 + sidx + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(fa, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      for (int sidx = 0; sidx < n; sidx += 2) {
+        step(fa, fb, isB, sidx, n, g0 + sidx);
+        if (sidx + 1 < n) step(fb, fa, isB, sidx + 1, n, g0 + sidx + 1);
+      }
     }
   };
 

@@ -6,7 +6,7 @@ i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" "SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
   rm -rf /tmp/pg$i
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pg$i -o p --output-format csv -- python scripts/dev/gemm_bench.py > gpurun_out/pmcg/run$i.log 2>&1 || tail -3 gpurun_out/pmcg/run$i.log
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $set -d /tmp/pg$i -o p --output-format csv -- python ${PMC_SCRIPT:-scripts/dev/gemm_bench.py} > gpurun_out/pmcg/run$i.log 2>&1 || tail -3 gpurun_out/pmcg/run$i.log
   python - $i <<'PY'
 import csv, glob, sys, collections
 i = sys.argv[1]
