@@ -17,19 +17,25 @@ steps_in_pmc = 4.0            # 1 warm-up + 2 timed + 1 roofline-leg step in the
 traffic = (f"{(ft + wt) / steps_in_pmc / 1e9:.0f} GB per step in total (≈ {(ft + wt) / steps_in_pmc / 1e9 / d['ms_per_step']:.1f} TB/s average); the dominant kernel "
            f"moves {(fd + wd) / n / 1e6:.0f} MB per launch against {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (operands once + outputs), i.e. "
            f"{(fd + wd) / n / r['algorithmic_bytes_per_launch']:.2f}×")
-p5 = json.load(open(f"{P}/r02_fullsize_parity_diffmusic_style_audioldm2.json")) if os.path.exists(f"{P}/r02_fullsize_parity_diffmusic_style_audioldm2.json") else None
-f = lambda v: f"{v:.1e}".replace("e-0", "e-")
+f = lambda v: f"{v:.1e}".replace("e-0", "e-") if v else "0"
+mf = {x["kernel"]: x for x in csv.DictReader(open(f"{P}/r02_pmc_mfma_util_per_kernel.csv"))} if os.path.exists(f"{P}/r02_pmc_mfma_util_per_kernel.csv") else {}
+dom_mf = [x for k, x in mf.items() if k.startswith("gemm_glds_kernel<") and int(k.split("<")[1].split(",")[0]) >= 192]
+mfma_util = (sum(float(x["SQ_VALU_MFMA_BUSY_CYCLES_total"]) for x in dom_mf) / (4.0 * sum(float(x["SQ_BUSY_CU_CYCLES_total"]) for x in dom_mf))) if dom_mf else 0.0
 rep = {"VALUE": f"{d['value']:.2f}", "MS": f"{d['ms_per_step']:.1f}", "CLIPS": f"{d['config']['clip_steps_per_sec']:.0f}", "RATIO": f"{cb['gpu_over_cpu']:.0f}",
+       "CPUMODEL": cb.get("cpu_model", "host CPU"), "CPU1": f"{cb['batch1_seconds_per_step']:.2f}", "CPU8": f"{cb['batch8_seconds_per_step']:.1f}", "CPUVAL": f"{cb['value']:.3f}",
        "STAGES": stages, "DOMMS": f"{r['kernel_ms_per_step']:.1f}", "DOMTF": f"{r['achieved']:.0f}", "DOMFRAC": f"{100 * r['frac']:.1f} %",
+       "NLAUNCH": str(r['all_gemm_kernels']['launches_per_step']), "DOMN": str(r['launches_per_step']), "DOMALGO": f"{r['algorithmic_tflop_per_step']:.1f}",
+       "MFMAUTIL": f"{100 * mfma_util:.0f} %",
        "ALLTF": f"{r['all_gemm_kernels']['achieved']:.0f}", "STEPTF": f"{r['whole_step']['achieved']:.0f}", "TRAFFIC": traffic,
        "MELMS": f"{d['mel_path']['stage_ms']:.2f}", "MELGB": f"{d['mel_path']['achieved_GBps']:.0f}", "MELFRAC": f"{100 * d['mel_path']['frac']:.1f} %",
        "W3": f"{w['dsg_phase_audioldm2']['value']:.1f}", "W4": f"{w['mpgd_sr4']['value']:.1f}", "W5": f"{w['diffmusic_style_audioldm2']['value']:.1f}",
        "FDEC": f"{d['after_loop']['final_decode_ms']:.0f}"}
-if p5:
-    rep.update({"P5EPS": f(p5["unet_eps"]), "P5VAE": f"{f(p5['vae_mel'])} / {f(p5['vae_bwd'])}",
-                "P5VOC": f"{f(p5['vocoder_wav'])} / {f(p5['vocoder_bwd'])} ({p5['vocoder_bwd_cos']:.4f})",
-                "P5OP": f"{f(p5['operator_loss'])} / {f(p5['operator_bwd'])}",
-                "P5STEP": f"{f(p5['step_loss'])} / {f(p5['step_grad'])} ({p5['step_grad_cos']:.4f}) / {f(p5['step_prev_sample'])}"})
+for tag, name in (("P2", "dps_inpainting"), ("P3", "dsg_phase_audioldm2"), ("P4", "mpgd_sr4"), ("P5", "diffmusic_style_audioldm2")):
+    q = json.load(open(f"{P}/r02_fullsize_parity_{name}.json"))
+    rep.update({tag + "EPS": f(q["unet_eps"]), tag + "VAE": f"{f(q['vae_mel'])} / {f(q['vae_bwd'])}",
+                tag + "VOC": f"{f(q['vocoder_wav'])} / {f(q['vocoder_bwd'])} ({q['vocoder_bwd_cos']:.4f})",
+                tag + "OP": f"{f(q['operator_loss'])} / {f(q['operator_bwd'])}",
+                tag + "STEP": f"{f(q['step_loss'])} / {f(q['step_grad'])} ({q['step_grad_cos']:.4f}) / {f(q['step_prev_sample'])}"})
 s = open("DESIGN.template.md").read()
 for k, v in rep.items():
     s = s.replace(f"@@{k}@@", v)

@@ -23,4 +23,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage-times > $out/pmc_$c.log 2>&1 || tail -3 $out/pmc_$c.log
   python scripts/dev/pmc_summary.py /tmp/pmc_$c $c $out/${tag}_pmc_${c}_per_kernel.csv | head -8
 done
+# MFMA-pipe utilisation per kernel (north_star: "MFMA utilisation on the attention / conv path"): cycles the matrix pipe of a SIMD is
+# busy / cycles its CU is busy, one more separate --pmc pass
+rm -rf /tmp/pmc_mfma
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -d /tmp/pmc_mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage-times > $out/pmc_mfma.log 2>&1 || tail -3 $out/pmc_mfma.log
+python scripts/dev/pmc_mfma_summary.py /tmp/pmc_mfma $out/${tag}_pmc_mfma_util_per_kernel.csv | head -12
 ls -la $out
