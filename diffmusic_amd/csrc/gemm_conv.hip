@@ -211,23 +211,35 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   // input for this row (conv zero padding, rows past M: mask 0) -- two masks per register.  The K loop then needs one bit test
   // per row and step instead of two coordinate adds and two range compares, and 3 instead of 10 registers for A_ISS = 5.
   unsigned a_lin[A_ISS], a_mask2[(A_ISS + 1) / 2];
+  {
+    int r_iy[A_ISS], r_ix[A_ISS];            // prologue only: the K loop keeps a_lin and the masks
+    unsigned r_mask[A_ISS];
 #pragma unroll
-  for (int i = 0; i < (A_ISS + 1) / 2; ++i) a_mask2[i] = 0u;
-#pragma unroll
-  for (int i = 0; i < A_ISS; ++i) {
-    const int m = m0 + (i * NW + wave) * 8 + lrow;
-    unsigned mask = 0u;
-    a_lin[i] = 0u;
-    if (m < p.M) {
-      const int b = m / HqWq, rem = m - b * HqWq;
-      const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
-      const int iy = qy * p.sy, ix = qx * p.sx;
-      a_lin[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * lda2 + (unsigned)(iy * p.Wi + ix) * lda2 + ((unsigned)cc << 4);
-#pragma unroll
-      for (int t = 0; t < DMX_MAX_TAPS; ++t)
-        if (t < p.ntaps && (unsigned)(iy + p.tdy[t]) < (unsigned)p.Hi && (unsigned)(ix + p.tdx[t]) < (unsigned)p.Wi) mask |= 1u << t;
+    for (int i = 0; i < A_ISS; ++i) {
+      const int m = m0 + (i * NW + wave) * 8 + lrow;
+      r_mask[i] = 0u; a_lin[i] = 0u;
+      r_iy[i] = -(1 << 20); r_ix[i] = 0;
+      if (m < p.M) {
+        int b = 0, qy = 0, qx = m;                                   // plain GEMM rows (one "image" of M x 1 pixels): no divisions
+        if (!(p.Hq == 1 && p.Wq >= p.M)) {
+          b = m / HqWq; const int rem = m - b * HqWq;
+          qy = rem / p.Wq; qx = rem - qy * p.Wq;
+        }
+        r_iy[i] = qy * p.sy; r_ix[i] = qx * p.sx;
+        a_lin[i] = (unsigned)b * (unsigned)(p.Hi * p.Wi) * lda2 + (unsigned)(r_iy[i] * p.Wi + r_ix[i]) * lda2 + ((unsigned)cc << 4);
+      }
     }
-    a_mask2[i >> 1] |= mask << ((i & 1) * 16);
+    for (int t = 0; t < p.ntaps; ++t) {       // wave-uniform trip count: a plain GEMM pays for one tap, not sixteen
+      const int tv = __builtin_amdgcn_readlane(tapreg, t);
+      const int dy = (int)(signed char)(tv & 0xff), dx = (int)(signed char)((tv >> 8) & 0xff);
+#pragma unroll
+      for (int i = 0; i < A_ISS; ++i)
+        if ((unsigned)(r_iy[i] + dy) < (unsigned)p.Hi && (unsigned)(r_ix[i] + dx) < (unsigned)p.Wi) r_mask[i] |= 1u << t;
+    }
+#pragma unroll
+    for (int i = 0; i < (A_ISS + 1) / 2; ++i) a_mask2[i] = 0u;
+#pragma unroll
+    for (int i = 0; i < A_ISS; ++i) a_mask2[i >> 1] |= r_mask[i] << ((i & 1) * 16);
   }
   // weight rows: instruction j fetches row tn * BN + (j * NW + wave) * 8 + lrow; rows past N lie beyond the descriptor's range
   // (num_records = N rows) and come back as zeros
