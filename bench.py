@@ -205,6 +205,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--settle", type=int, default=10, help="throw-away conditioning steps (full loop body, on a copy of the latents) before the "
+                    "W warm-up steps; 0 = none.  They absorb one-time costs that would otherwise land in a short timed region whatever W is: "
+                    "first-call initialisation (~0.2-0.4 s) and the lazy load of the torch kernels of the NaN check (~30 ms); DESIGN.md section 4")
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the second CPU leg (0 = 8 if host memory allows, else 4 / 2 / none)")
@@ -254,9 +257,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- conditioning, outside the contract's W warm-up + K timed steps: the full loop body on a throw-away copy of the latents, so that
+    # one-time costs cannot land in the timed region whatever W is.  Measured on fresh boxes: the first step of a process takes 0.2-0.4 s
+    # (library initialisation), and the first torch.isnan(...).any() of a process loads torch's elementwise kernels lazily (~30 ms: it
+    # used to fall into the timed loop and read as "the first process on a box is 3-6 ms/step slower", 44.8 -> 41.0 ms over 10 steps).
+    # The trajectory that is warmed up and timed below starts from the untouched latents.
+    settle_ms = []
+    if args.settle > 0:
+        lat_c = latents.clone()
+        se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(args.settle):
+            se0.record()
+            lat_c, loss_c = one_step(pipe, lat_c, ts[i % n_sched], pe2, measurement, L)
+            se1.record()
+            if not args.no_nan_check:        # the whole loop body, host check included: its torch kernels are loaded lazily on first use
+                bool(torch.isnan(loss_c).any())      # (measured: ~30 ms once per process on a fresh box -- 3 ms/step over a 10-step timed region)
+            torch.cuda.synchronize()
+            settle_ms.append(se0.elapsed_time(se1))
+        del lat_c
     k = 0
-    for _ in range(args.warmup):
-        latents, _ = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
+    for _ in range(args.warmup):             # the same body as the timed loop below
+        latents, loss_w = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
+        if not args.no_nan_check:
+            bool(torch.isnan(loss_w).any())
         k += 1
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -354,7 +377,8 @@ def main():
                "config": {"workload": wl_text, "global_batch": B * world, "clips_per_gpu": B,
                           "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world} ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL'} world size {world}, no per-step collective)",
                           "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_steps": nan_steps,
-                          "nan_check_per_step": not args.no_nan_check, "final_loss_clip0": float(loss.reshape(-1)[0]),
+                          "nan_check_per_step": not args.no_nan_check,
+                          "settle_steps": len(settle_ms), "settle_first3_ms": [round(v, 2) for v in settle_ms[:3]], "settle_last3_ms": [round(v, 2) for v in settle_ms[-3:]], "final_loss_clip0": float(loss.reshape(-1)[0]),
                           "cached_reference_transform": bool(getattr(op, "cache_reference", False)),
                           "unet_hip_graph": bool(getattr(pipe.unet, "use_graph", False)),
                           "launched_by": "bench.py spawn" if os.environ.get("DMX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
