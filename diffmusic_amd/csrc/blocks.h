@@ -149,12 +149,10 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
   // scores are written by the GEMM epilogue as fp16 straight into the P buffer (row pitch Nkp) and soft-maxed in place:
   // half the HBM traffic of an fp32 score matrix (the N = 1000 U-Net levels are write-bound on it)
   static const bool fused_ok = getenv("DMX_NO_FLASH") == nullptr;
-  if (!P_keep && fused_ok && dmx_flash_attn_ok(dh, C, Nkp)) {
-    // forward-only callers (the U-Net): no score matrix at all -- flash_attn.hip walks the keys with an online softmax
-    act_t* vT = A.bf((size_t)Z * dh * Nkp);
-    if (Nkp != Nk && !cx.dry) (void)hipMemsetAsync(vT, 0, (size_t)Z * dh * Nkp * sizeof(act_t), cx.st);
-    CRUN(dmx_transpose(v, vT, Nk, dh, ldv, Nkp, Z, heads, (long long)Nk * ldv, dh, (long long)heads * dh * Nkp, (long long)dh * Nkp, cx.st));
-    CRUN(dmx_flash_attn_fwd(q, k, vT, o, colbias, B, Nq, Nk, Nkp, C, heads, scale, cx.st, ldq, ldk));
+  if (!P_keep && fused_ok && dmx_flash_attn_ok(dh, C)) {
+    // forward-only callers (the U-Net): no score matrix at all -- flash_attn.hip walks the keys with an online softmax and takes
+    // q, k, v as they come out of the projections (V is transposed inside the kernel on its way into LDS)
+    CRUN(dmx_flash_attn_fwd(q, k, v, o, colbias, B, Nq, Nk, C, heads, scale, cx.st, ldq, ldk, ldv));
     A.release(mk);
     return DMX_OK;
   }

@@ -126,10 +126,10 @@ int dmx_conv_pair_group_raw(int n, const void* descs_a, const void* descs_b, siz
   return rc;
 }
 
-int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, const float* colbias, int B, int Nq, int Nk, int Nkp, int C,
+int dmx_flash_attn_raw(const void* q, const void* k, const void* v, void* o, const float* colbias, int B, int Nq, int Nk, int ldv, int C,
                        int heads, float scale, void* stream) {
-  const int rc = dmx_flash_attn_fwd((const act_t*)q, (const act_t*)k, (const act_t*)vT, (act_t*)o, colbias, B, Nq, Nk, Nkp, C, heads, scale,
-                                    ST(stream));
+  const int rc = dmx_flash_attn_fwd((const act_t*)q, (const act_t*)k, (const act_t*)v, (act_t*)o, colbias, B, Nq, Nk, C, heads, scale,
+                                    ST(stream), 0, 0, ldv);
   if (rc == DMX_ERR_SHAPE) dmx_set_error("flash attention: unsupported head_dim / strides");
   return rc;
 }

@@ -39,9 +39,9 @@ struct FaCfg {
 };
 
 struct FaParams {
-  const act_t* q; const act_t* k; const act_t* vT; act_t* o;
+  const act_t* q; const act_t* k; const act_t* v; act_t* o;
   const float* colbias;
-  int Nq, Nk, Nkp, C, heads, dh, ldq, ldk;      // C = row stride of o; ldq / ldk = row strides of q / k (a fused QKV buffer has 3C)
+  int Nq, Nk, C, heads, dh, ldq, ldk, ldv;      // C = row stride of o; ldq / ldk / ldv = row strides of q / k / v (a fused QKV buffer has 3C)
   float c;                    // scale * log2(e)
 };
 
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
   const int ldq = P.ldq, ldk = P.ldk;
   const act_t* qb = P.q + (long long)b * P.Nq * ldq + h * dh;
   const act_t* kb = P.k + (long long)b * Nk * ldk + h * dh;
-  const act_t* vb = P.vT + (long long)z * dh * P.Nkp;
+  const act_t* vb = P.v + (long long)b * Nk * P.ldv + h * dh;
   const float NEG = -__builtin_huge_valf();
 
   // ---- Q fragments (B operand): lane (lr, lq) holds q[query 16*qt + lr][32*ks + 8*lq .. +8]
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
     }
 #pragma unroll
     for (int it = 0; it < F::VIT; ++it) {
-      const int c = tid + it * 256, row = c >> 3, key = key0 + (c & 7) * 8;
+      // V arrives row-major (key, d) like K and is transposed on its way into LDS (lstore): chunk c = 8 d-values of one key
+      const int c = tid + it * 256, kl = c / (2 * DT), d = (c - kl * (2 * DT)) * 8;
       vreg[it] = make_uint4(0, 0, 0, 0);
-      if (c < F::VCH && row < dh && key < P.Nkp) vreg[it] = *reinterpret_cast<const uint4*>(vb + (long long)row * P.Nkp + key);
+      if (c < F::VCH && d < dh && key0 + kl < Nk) vreg[it] = *reinterpret_cast<const uint4*>(vb + (long long)(key0 + kl) * P.ldv + d);
     }
   };
   auto lstore = [&](int buf) {
@@ -99,8 +100,13 @@ __global__ __launch_bounds__(256) void flash_attn_fwd_kernel(const FaParams P) {
     }
 #pragma unroll
     for (int it = 0; it < F::VIT; ++it) {
-      const int c = tid + it * 256;
-      if (c < F::VCH) *reinterpret_cast<uint4*>(vt + (c >> 3) * F::VPITCH + (c & 7) * 16) = vreg[it];
+      const int c = tid + it * 256, kl = c / (2 * DT), d = (c - kl * (2 * DT)) * 8;
+      if (c < F::VCH) {                         // V^T tile [d][key]: eight 2-byte stores (rows d .. d + 7, column kl); keys past Nk and d >= dh are zeros
+        const uint32_t w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          *reinterpret_cast<act_t*>(vt + (d + e) * F::VPITCH + kl * 2) = (act_t)((e & 1) ? (w[e >> 1] >> 16) : (w[e >> 1] & 0xffffu));
+      }
     }
   };
 
@@ -240,19 +246,20 @@ int launch_fa(const FaParams& P, int Z, hipStream_t st) {
 
 }  // namespace
 
-bool dmx_flash_attn_ok(int dh, int C, int Nkp) { return dh >= 8 && dh <= 96 && (dh & 3) == 0 && (dh & 7) == 0 && (C & 7) == 0 && (Nkp & 7) == 0; }
+bool dmx_flash_attn_ok(int dh, int C) { return dh >= 8 && dh <= 96 && (dh & 7) == 0 && (C & 7) == 0; }
 
-// q (B, Nq, ldq), k (B, Nk, ldk) channels-last (row strides ldq / ldk >= C; 0 = C) with `heads` heads of dh = C / heads; vT (B*heads, dh, Nkp) = per-head V^T with
-// zero columns in [Nk, Nkp); o (B, Nq, C).  colbias: optional additive key bias (B, Nk) fp32.
-int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* vT, act_t* o, const float* colbias, int B, int Nq, int Nk,
-                       int Nkp, int C, int heads, float scale, hipStream_t st, int ldq, int ldk) {
+// q (B, Nq, ldq), k (B, Nk, ldk), v (B, Nk, ldv) channels-last (row strides >= C; 0 = C) with `heads` heads of dh = C / heads; o (B, Nq, C).
+// colbias: optional additive key bias (B, Nk) fp32.  V is transposed inside the kernel on its way into LDS: no V^T tensor, no transpose launch.
+int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* v, act_t* o, const float* colbias, int B, int Nq, int Nk,
+                       int C, int heads, float scale, hipStream_t st, int ldq, int ldk, int ldv) {
   const int dh = C / heads;
   if (ldq <= 0) ldq = C;
   if (ldk <= 0) ldk = C;
-  if (!dmx_flash_attn_ok(dh, C, Nkp) || Nq < 1 || Nk < 1 || (ldq & 7) || (ldk & 7)) return DMX_ERR_SHAPE;
+  if (ldv <= 0) ldv = C;
+  if (!dmx_flash_attn_ok(dh, C) || Nq < 1 || Nk < 1 || (ldq & 7) || (ldk & 7) || (ldv & 7)) return DMX_ERR_SHAPE;
   FaParams P;
-  P.q = q; P.k = k; P.vT = vT; P.o = o; P.colbias = colbias;
-  P.Nq = Nq; P.Nk = Nk; P.Nkp = Nkp; P.C = C; P.heads = heads; P.dh = dh; P.ldq = ldq; P.ldk = ldk;
+  P.q = q; P.k = k; P.v = v; P.o = o; P.colbias = colbias;
+  P.Nq = Nq; P.Nk = Nk; P.C = C; P.heads = heads; P.dh = dh; P.ldq = ldq; P.ldk = ldk; P.ldv = ldv;
   P.c = scale * 1.4426950408889634f;
   const int Z = B * heads;
   const int rec = dmx_prof_open(st);

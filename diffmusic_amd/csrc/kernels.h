@@ -42,9 +42,9 @@ int dmx_pad_col8_act(const act_t* v, act_t* y, long long rows, hipStream_t st);
 int dmx_timestep_embed(const float* t, act_t* y, int B, int dim, hipStream_t st);
 
 // ---- flash_attn.hip (forward-only fused attention for the U-Net)
-bool dmx_flash_attn_ok(int dh, int C, int Nkp);
-int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* vT, act_t* o, const float* colbias, int B, int Nq, int Nk,
-                       int Nkp, int C, int heads, float scale, hipStream_t st, int ldq = 0, int ldk = 0);
+bool dmx_flash_attn_ok(int dh, int C);
+int dmx_flash_attn_fwd(const act_t* q, const act_t* k, const act_t* v, act_t* o, const float* colbias, int B, int Nq, int Nk,
+                       int C, int heads, float scale, hipStream_t st, int ldq = 0, int ldk = 0, int ldv = 0);
 
 // ---- mel.hip (STFT / mel measurement path, fp32)
 int dmx_stft_tables(float* table, float* tableT, int n_fft, int bins, int Npad, int Kpad, int hann, hipStream_t st);

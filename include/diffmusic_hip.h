@@ -198,9 +198,9 @@ int dmx_gemm_raw(const void* desc, size_t desc_bytes, void* stream);
 /* test hook for the fused convolution pair (HiFi-GAN resblock step, C = 32 / 64): stage `a` (may be NULL: plain slab
  * convolution) feeds stage `b` through LDS.  Returns DMX_ERR_SHAPE when the shape is not handled by the fused kernel. */
 /* test hook for the fused forward attention of the U-Net (diffusers Attention inside UNet2DConditionModel,
- * pipeline_musicldm.py:696-703): q (B,Nq,C), k (B,Nk,C) fp16 channels-last, vT (B*heads, C/heads, Nkp) per-head V^T with zero
- * columns past Nk, o (B,Nq,C); colbias optional (B,Nk) fp32 additive key bias. */
-int dmx_flash_attn_raw(const void* q, const void* k, const void* vT, void* o, const float* colbias, int B, int Nq, int Nk, int Nkp,
+ * pipeline_musicldm.py:696-703): q (B,Nq,C), k (B,Nk,C), v (B,Nk,ldv) fp16 channels-last (ldv = 0: C), o (B,Nq,C); colbias optional
+ * (B,Nk) fp32 additive key bias. */
+int dmx_flash_attn_raw(const void* q, const void* k, const void* v, void* o, const float* colbias, int B, int Nq, int Nk, int ldv,
                        int C, int heads, float scale, void* stream);
 /* test hook: fp32 scratch that lets small-M / deep-K launches run split-K (NULL disables it); the U-Net executor
  * installs its own */

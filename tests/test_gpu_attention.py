@@ -23,13 +23,10 @@ def test_flash_attention_forward(B, heads, dh, Nq, Nk, bias):
         cb = torch.where(torch.rand(B, Nk, generator=g) < 0.3, -10000.0, 0.0)
         cb[:, 0] = 0.0
         cb = cb.cuda().contiguous()
-    Nkp = (Nk + 7) // 8 * 8
-    vT = torch.zeros(B * heads, dh, Nkp, dtype=adt, device="cuda")
-    vT[:, :, :Nk] = v.view(B, Nk, heads, dh).permute(0, 2, 3, 1).reshape(B * heads, dh, Nk)
     o = torch.zeros(B, Nq, Cc, dtype=adt, device="cuda")
     scale = 1.0 / math.sqrt(dh)
-    L.check(L.lib().dmx_flash_attn_raw(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(vT.data_ptr()), C.c_void_p(o.data_ptr()),
-                                       C.c_void_p(cb.data_ptr()) if cb is not None else None, B, Nq, Nk, Nkp, Cc, heads, scale,
+    L.check(L.lib().dmx_flash_attn_raw(C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(v.data_ptr()), C.c_void_p(o.data_ptr()),
+                                       C.c_void_p(cb.data_ptr()) if cb is not None else None, B, Nq, Nk, 0, Cc, heads, scale,
                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "flash_attn")
     torch.cuda.synchronize()
     qf = q.float().view(B, Nq, heads, dh).transpose(1, 2)
