@@ -739,6 +739,17 @@ __global__ void copy_channels_kernel(const act_t* __restrict__ src, act_t* __res
   *reinterpret_cast<uint4*>(dst + r * ldd + doff + c) = *reinterpret_cast<const uint4*>(src + r * lds + soff + c);
 }
 
+// channel concat of two channels-last tensors in one launch: dst[r] = [a[r] (Ca channels) | b[r] (Cb channels)]
+__global__ void concat2_kernel(const act_t* __restrict__ a, const act_t* __restrict__ b, act_t* __restrict__ dst, long long rows, int Ca, int Cb) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cpr = (Ca + Cb) >> 3, ca8 = Ca >> 3;
+  if (idx >= rows * cpr) return;
+  const long long r = idx / cpr;
+  const int c = (int)(idx - r * cpr);
+  const uint4 v = c < ca8 ? *reinterpret_cast<const uint4*>(a + r * Ca + (c << 3)) : *reinterpret_cast<const uint4*>(b + r * Cb + ((c - ca8) << 3));
+  *reinterpret_cast<uint4*>(dst + r * (Ca + Cb) + (c << 3)) = v;
+}
+
 // y = a*x (+ b*y0)  over bf16
 __global__ void axpby_kernel(const act_t* __restrict__ x, const act_t* __restrict__ y0, act_t* __restrict__ y,
                              float a, float b, long long n8) {
@@ -1045,6 +1056,12 @@ int dmx_copy_channels(const act_t* src, act_t* dst, long long rows, int C, int l
   const long long n = rows * (C >> 3);
   hipLaunchKernelGGL(copy_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, rows, C, lds,
                      ldd, soff, doff);
+  return CHECK_LAUNCH();
+}
+int dmx_concat2(const act_t* a, const act_t* b, act_t* dst, long long rows, int Ca, int Cb, hipStream_t st) {
+  if ((Ca & 7) || (Cb & 7)) return DMX_ERR_SHAPE;
+  const long long n = rows * ((Ca + Cb) >> 3);
+  hipLaunchKernelGGL(concat2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, dst, rows, Ca, Cb);
   return CHECK_LAUNCH();
 }
 int dmx_axpby(const act_t* x, const act_t* y0, act_t* y, float a, float b, long long n, hipStream_t st) {

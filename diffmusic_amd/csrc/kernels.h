@@ -26,6 +26,7 @@ int dmx_upsample_nearest(const act_t* x, act_t* y, int B, int Hi, int Wi, int Ho
 int dmx_upsample2x_bwd(const act_t* dy, act_t* dx, int B, int Hi, int Wi, int C, hipStream_t st);
 int dmx_transpose(const act_t* in, act_t* out, int R, int C, long long ldi, long long ldo, int Z, int Zi, long long sIo,
                   long long sIi, long long sOo, long long sOi, hipStream_t st);
+int dmx_concat2(const act_t* a, const act_t* b, act_t* dst, long long rows, int Ca, int Cb, hipStream_t st);
 int dmx_copy_channels(const act_t* src, act_t* dst, long long rows, int C, int lds, int ldd, int soff, int doff,
                       hipStream_t st);
 int dmx_axpby(const act_t* x, const act_t* y0, act_t* y, float a, float b, long long n, hipStream_t st);

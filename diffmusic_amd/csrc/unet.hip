@@ -409,8 +409,7 @@ struct UNet : Model {
         act_t* y3 = (b.has_attn && napl > 1) ? A.bf((size_t)B * H * W * b.ch) : nullptr;
         const size_t mk = A.mark();
         act_t* cat = A.bf((size_t)B * H * W * cc);
-        CRUN(dmx_copy_channels(cur, cat, (long long)B * H * W, curC, curC, cc, 0, 0, st));
-        CRUN(dmx_copy_channels(s.p, cat, (long long)B * H * W, s.C, s.C, cc, 0, curC, st));
+        CRUN(dmx_concat2(cur, s.p, cat, (long long)B * H * W, curC, s.C, st));               // [hidden | skip] in one launch
         if (b.has_attn) {
           CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
           CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
