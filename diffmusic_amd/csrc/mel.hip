@@ -346,6 +346,38 @@ __global__ __launch_bounds__(1024) void absmax_normalize_kernel(float* __restric
   for (long long i = threadIdx.x; i < n; i += blockDim.x) p[i] *= s;
 }
 
+// The same in four short launches for long clips (one 1024-thread workgroup per clip walked 160 000 samples twice in 69 us):
+// memset(max) -> per-chunk maxima folded with an integer atomicMax (|x| >= 0: the bit pattern orders like the value, and a maximum does
+// not depend on the order of its operands -- still bit-reproducible) -> scale -> max replaced by 1 / scale.
+__global__ __launch_bounds__(256) void absmax_chunk_kernel(const float* __restrict__ x, unsigned* __restrict__ maxbits, long long n, long long per) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const float* p = x + (long long)b * n;
+  const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  float m = 0.f;
+  for (long long i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+    if (i + 4 <= i1) { const float4 v = *reinterpret_cast<const float4*>(p + i); m = fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fmaxf(fabsf(v.y), fabsf(v.z)), fabsf(v.w))); }
+    else for (long long k = i; k < i1; ++k) m = fmaxf(m, fabsf(p[k]));
+  }
+  m = block_max(m, sh);
+  if (threadIdx.x == 0) atomicMax(maxbits + b, __float_as_uint(m));
+}
+__device__ __forceinline__ float absmax_scale_of(float m, float target) { return (m > 0.f && isfinite(m)) ? target / m : 1.f; }
+__global__ __launch_bounds__(256) void absmax_scale_kernel(float* __restrict__ x, const float* __restrict__ maxv, long long n, long long per, float target) {
+  const int b = blockIdx.y;
+  float* p = x + (long long)b * n;
+  const float s = absmax_scale_of(maxv[b], target);
+  const long long i0 = (long long)blockIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+  for (long long i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+    if (i + 4 <= i1) { float4 v = *reinterpret_cast<float4*>(p + i); v.x *= s; v.y *= s; v.z *= s; v.w *= s; *reinterpret_cast<float4*>(p + i) = v; }
+    else for (long long k = i; k < i1; ++k) p[k] *= s;
+  }
+}
+__global__ void absmax_finish_kernel(float* __restrict__ inv_scale, int B, float target) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) inv_scale[b] = 1.f / absmax_scale_of(inv_scale[b], target);
+}
+
 }  // namespace
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH)
@@ -418,6 +450,15 @@ int dmx_melscale(const float* mag, const float* fb, float* mel, int B, int T, in
   return CHECK_LAUNCH();
 }
 int dmx_absmax_normalize(float* x, float* inv_scale, int B, long long n, float target, hipStream_t st) {
-  hipLaunchKernelGGL(absmax_normalize_kernel, dim3(B), dim3(1024), 0, st, x, inv_scale, n, target);
+  if (n < 32768 || (n & 3) || ((uintptr_t)x & 15)) {            // short or unaligned clips: one workgroup per clip
+    hipLaunchKernelGGL(absmax_normalize_kernel, dim3(B), dim3(1024), 0, st, x, inv_scale, n, target);
+    return CHECK_LAUNCH();
+  }
+  const int chunks = (int)((n + 8191) / 8192);                  // 8192 samples per workgroup (a multiple of 4: chunks stay 16-byte aligned)
+  const long long per = 8192;
+  (void)hipMemsetAsync(inv_scale, 0, (size_t)B * sizeof(float), st);
+  hipLaunchKernelGGL(absmax_chunk_kernel, dim3(chunks, B), dim3(256), 0, st, x, reinterpret_cast<unsigned*>(inv_scale), n, per);
+  hipLaunchKernelGGL(absmax_scale_kernel, dim3(chunks, B), dim3(256), 0, st, x, inv_scale, n, per, target);
+  hipLaunchKernelGGL(absmax_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, st, inv_scale, B, target);
   return CHECK_LAUNCH();
 }

@@ -198,3 +198,24 @@ def test_scheduler_device_noise_option():
     assert torch.equal(ref.step(e, 496, x, sample_noise=z2, **kw).prev_sample, a2)
     host = ref.step(e, 501, x, generator=gens(), **kw).prev_sample
     assert not torch.equal(host, a1)                                                # the default stays torch's generator stream
+
+
+@pytest.mark.parametrize("B,n", [(8, 160000), (3, 160004), (2, 1000), (4, 40001)])
+def test_grad_normalize_scales_each_clip_to_the_target(B, n):
+    """dmx_grad_normalize (the per-clip rescale that keeps fp16 gradients in range before the vocoder backward): max|x| == target per clip,
+    inv_scale undoes it exactly, long clips (parallel chunk maxima) and short / unaligned ones (one workgroup per clip) agree with torch."""
+    import ctypes as C
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(B, n, generator=g) * torch.logspace(-6, 2, B).unsqueeze(1)).cuda().contiguous()
+    x[0, n // 3] = -7.5e3                                   # the maximum may be negative and sit anywhere
+    ref = x.clone()
+    inv = torch.empty(B, device="cuda")
+    L.check(L.lib().dmx_grad_normalize(C.c_void_p(x.data_ptr()), C.c_void_p(inv.data_ptr()), B, n, 64.0,
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)), "grad_normalize")
+    torch.cuda.synchronize()
+    m = ref.abs().amax(dim=1)
+    s = 64.0 / m
+    assert torch.allclose(x, ref * s.unsqueeze(1), rtol=1e-6, atol=0)
+    assert torch.allclose(inv, 1.0 / s, rtol=1e-6, atol=0)
+    assert torch.allclose(x.abs().amax(dim=1), torch.full((B,), 64.0, device="cuda"), rtol=1e-6)
