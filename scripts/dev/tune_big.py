@@ -5,7 +5,7 @@ from tune_tiles import time_cfg
 from diffmusic_amd import _lib as L
 shapes = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    if int(r["cfg"]) in (20, 21, 30) or int(r["cfg"]) >= 40: continue
+    if int(r["cfg"]) in (20, 21, 22, 30) or int(r["cfg"]) >= 40: continue
     key = (int(r["M"]), int(r["N"]), int(r["K"]), int(r["Z"]))
     s = shapes.setdefault(key, dict(taps=int(r["taps"]), flags=int(r["flags"]), ms=0.0, n=0, cfg=int(r["cfg"])))
     s["ms"] += float(r["ms"]); s["n"] += 1
@@ -17,6 +17,7 @@ for (M, N, K, Z), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
         if c in (1, 7, 8) and N % 256: continue
         try: res[c] = time_cfg(M, N, K, Z, s["taps"], s["flags"], c, 4)
         except Exception: pass
+    if not res: continue
     best = min(res, key=res.get)
     cur = res.get(s["cfg"], s["ms"] / s["n"])
     saved += (cur - res[best]) * s["n"]
