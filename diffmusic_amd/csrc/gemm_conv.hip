@@ -627,7 +627,12 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     if (best && best != 3) return launch_by_cfg(best, d, stream);
   }
   // small problems: 64x64 tiles so that at least ~1 block per CU exists (U-Net levels with 1k-4k pixels)
-  if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) return launch_by_cfg(6, d, stream);
+  if (d.N > 32 && (long long)cdiv(d.M, 128) * cdiv(d.N, 128) * d.Z < 200) {
+    // shapes the measured table does not know (other batch sizes / clip lengths): what the tuner found on ~150 of them -- the 4-stage LDS-DMA
+    // 64-row tiles win from K >= 512 on (64x128 when N allows it and there are rows enough), the register-staged tile below that
+    if (gl && d.K >= 512 && d.Z == 1) return launch_by_cfg(d.N % 128 == 0 && d.M >= 4000 ? 14 : 12, d, stream);
+    return launch_by_cfg(6, d, stream);
+  }
   if (d.N > 64) return launch_by_cfg(3, d, stream);
   if (d.N > 32) return launch_by_cfg(4, d, stream);
   return launch_by_cfg(5, d, stream);
