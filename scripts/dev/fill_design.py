@@ -13,7 +13,7 @@ def pmc(c):
     dom = [x for x in rows if x["kernel"].startswith("gemm_glds_kernel<") and int(x["kernel"].split("<")[1].split(",")[0]) >= 192]
     return tot, sum(float(x[f"{c}_bytes_total"]) for x in dom), sum(int(x["launches"]) for x in dom)
 ft, fd, n = pmc("FETCH_SIZE"); wt, wd, _ = pmc("WRITE_SIZE")
-steps_in_pmc = 4.0            # 1 warm-up + 2 timed + 1 roofline-leg step in the profiled command (+ the final decode)
+steps_in_pmc = 4.0 + d['config'].get('settle_steps', 0)      # conditioning + 1 warm-up + 2 timed + 1 roofline-leg step in the profiled command (+ the final decode)
 traffic = (f"{(ft + wt) / steps_in_pmc / 1e9:.0f} GB per step in total (≈ {(ft + wt) / steps_in_pmc / 1e9 / d['ms_per_step']:.1f} TB/s average); the dominant kernel "
            f"moves {(fd + wd) / n / 1e6:.0f} MB per launch against {r['algorithmic_bytes_per_launch'] / 1e6:.0f} MB algorithmic (operands once + outputs), i.e. "
            f"{(fd + wd) / n / r['algorithmic_bytes_per_launch']:.2f}×")

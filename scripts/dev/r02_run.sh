@@ -16,7 +16,7 @@ python - <<PY
 import csv
 rows=list(csv.DictReader(open('$out/r02_bench_${tag}_kernel_stats.csv')))
 tot=sum(float(r['TotalDurationNs']) for r in rows)
-print('kernel ms per step (7 steps incl. warm-up/profiled + final decode)', tot/1e6/7)
+print('kernel ms per step (17 steps: 10 conditioning + warm-up + timed + profiled, + final decode)', tot/1e6/17)
 for r in rows[:24]:
-    print(f"{r['Name'][:70].replace('(anonymous namespace)::',''):70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6/7:8.3f} ms/step {r['Percentage']}%")
+    print(f"{r['Name'][:70].replace('(anonymous namespace)::',''):70s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6/17:8.3f} ms/step {r['Percentage']}%")
 PY
