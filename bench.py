@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Headline benchmark: denoising steps/sec, MusicLDM + DPS music_inpainting, 10 s @16 kHz clips,
-200-step schedule, batch 8 per GPU (BASELINE.json configs[1]).  One "step" = one pass of the hot loop
+200-step schedule, batch 8 per GPU (BASELINE.json configs[1]; --batch / --global-batch / --workload select other cases).  One "step" = one pass of the hot loop
 over the batch: U-Net on the 2B CFG batch -> CFG combine -> DPSScheduler.step (x0, VAE decode,
 HiFi-GAN, mask, log-mel, L2, hand-written backward sweep, fused update).
 
@@ -61,7 +61,9 @@ WORKLOADS = {
 WORKLOAD_STEPS = {"diffmusic_style_audioldm2": 500}
 
 
-def build_problem(B, rank, device, workload="dps_inpainting"):
+def build_problem(B, rank, device, workload="dps_inpainting", clip_ids=None):
+    """Pipeline + operator + measurement + latents + conditioning of `B` clips.  `clip_ids` (default rank*B ... rank*B + B - 1) are the
+    GLOBAL clip numbers: clip k's audio, latent noise and generator depend on k only, never on how the clips are split over ranks."""
     from diffmusic_amd.pipelines import get_pipeline
     from diffmusic_amd.schedulers import get_scheduler
     from diffmusic_amd import inverse_problem as P
@@ -80,18 +82,23 @@ def build_problem(B, rank, device, workload="dps_inpainting"):
     pipe.scheduler = get_scheduler(sname)(operator=op, **SCHED_CFG)
     pipe.scheduler.set_timesteps(WORKLOAD_STEPS.get(workload, N_STEPS), device=device)
     L = SECONDS * SR
-    clips = torch.stack([synth_clip(rank * B + i, L) for i in range(B)]).to(device)
+    if clip_ids is None:
+        clip_ids = [rank * B + i for i in range(B)]
+    assert len(clip_ids) == B
+    clips = torch.stack([synth_clip(k, L) for k in clip_ids]).to(device)
     measurement = op.forward(clips)
-    gens = [torch.Generator().manual_seed(rank * B + i) for i in range(B)]
+    gens = [torch.Generator().manual_seed(k) for k in clip_ids]
     latents = randn_tensor((B, 8, 250, 16), generator=gens, device=device, dtype=torch.float32)
-    g7 = torch.Generator().manual_seed(7)
+    # conditioning rows are keyed by the global clip number too (row k of a seeded draw), so a clip's trajectory does not depend on the split
+    n_all = max(clip_ids) + 1
+    g7, g8 = torch.Generator().manual_seed(7), torch.Generator().manual_seed(8)
     if pname == "musicldm":
-        pe = torch.nn.functional.normalize(torch.randn(B, 512, generator=g7), dim=-1).to(device)
+        pe = torch.nn.functional.normalize(torch.randn(n_all, 512, generator=g7), dim=-1)[clip_ids].to(device)
         cond = dict(class_labels=torch.cat([pe, pe], dim=0))      # prompt="" in the reference: cond == uncond, CFG batch kept at 2B
         gscale = GUIDANCE_SCALE
     else:                                                          # AudioLDM2: GPT-2 states (B,8,768), T5 states (B,16,1024), mask ones
-        ge = torch.randn(B, 8, 768, generator=g7).to(device)
-        te = torch.randn(B, 16, 1024, generator=g7).to(device)
+        ge = torch.randn(n_all, 8, 768, generator=g7)[clip_ids].to(device)
+        te = torch.randn(n_all, 16, 1024, generator=g8)[clip_ids].to(device)
         cond = dict(class_labels=None, encoder_hidden_states=torch.cat([ge, ge]), encoder_hidden_states_1=torch.cat([te, te]),
                     encoder_attention_mask_1=torch.ones(2 * B, 16, device=device))
         gscale = 3.5
@@ -119,9 +126,9 @@ def cpu_model_string():
     return "unknown"
 
 
-def cpu_baseline(seed_sd, threads, batch):
+def cpu_baseline(seed_sd, threads, batch, n_meas):
     """The CPU restatement (oracle/, fp32 eager torch + autograd) timed on the host cores: `batch` clips, DPS steps.
-    Returns seconds per (batch-`batch`) step: 1 warm-up + 3 measured at batch 1, one measured step at larger batches."""
+    Returns seconds per (batch-`batch`) step over `n_meas` measured steps after 1 warm-up step."""
     from oracle import models as OM, operators as OO, schedulers as OS
     torch.set_num_threads(threads)
     unet, vae, voc = OM.UNetMusicLDM().eval(), OM.VaeDecoder().eval(), OM.HifiGan().eval()
@@ -136,7 +143,7 @@ def cpu_baseline(seed_sd, threads, batch):
     x = torch.cat([torch.randn(1, 8, 250, 16, generator=torch.Generator().manual_seed(i)) for i in range(batch)])
     pe = torch.nn.functional.normalize(torch.randn(batch, 512, generator=torch.Generator().manual_seed(7)), dim=-1)
     ts = [int(t) for t in sched.timesteps]
-    n_warm, n_meas = (1, 3) if batch == 1 else (0, 1)
+    n_warm = 1
     t0 = time.perf_counter()
     for i in range(n_warm + n_meas):
         if i == n_warm:
@@ -178,26 +185,75 @@ def pmc_traffic(prefix):
     return (round(tot / n) if n else None), src + ")"
 
 
-def spawn_ranks(n, argv, need_gpus):
-    """--gpus N without a launcher: N fresh rank processes (this parent never touches the GPU), RCCL rendezvous on 127.0.0.1."""
+def visible_gpus():
+    """Number of GPUs this process may use, WITHOUT bringing up the HIP runtime in the parent (its children must be the first
+    processes to touch the GPU): KFD topology nodes that have SIMDs, cut down by HIP_/ROCR_VISIBLE_DEVICES lists."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for d in os.listdir(base):
+            with open(os.path.join(base, d, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except OSError:
+        return None                                       # unknown here: let the ranks report a shortfall themselves
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def spawn_ranks(n, argv, need_gpus, timeout_s=3300.0):
+    """--gpus N without a launcher: N fresh rank processes (this parent never touches the GPU), RCCL rendezvous on 127.0.0.1.
+    The children are polled: when one exits non-zero (or the deadline passes) the survivors are terminated, so nobody is left
+    waiting in a rendezvous or barrier; a rendezvous port that another process grabbed first is retried on a new port."""
     import socket
-    have = torch.cuda.device_count()                  # counting devices does not initialise the GPU
-    if have < need_gpus:
+    have = visible_gpus()
+    if have is not None and have < need_gpus:
         print(f"[bench] --gpus {n} but only {have} GPU(s) are visible", file=sys.stderr)
         return 3
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), DMX_BENCH_SPAWNED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
-    rcs = [p.wait() for p in procs]
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
+    for attempt in range(3):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), DMX_BENCH_SPAWNED="1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+        deadline = time.monotonic() + timeout_s
+        rcs = [None] * n
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+            failed = [rc for rc in rcs if rc not in (None, 0)]
+            if failed or time.monotonic() > deadline:
+                for r, p in enumerate(procs):              # exactly the PIDs started above
+                    if rcs[r] is None:
+                        p.terminate()
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        try:
+                            rcs[r] = p.wait(timeout=15)
+                        except subprocess.TimeoutExpired:
+                            p.kill()
+                            rcs[r] = p.wait()
+                if not failed:
+                    print(f"[bench] ranks did not finish within {timeout_s:.0f} s", file=sys.stderr)
+                    return 5
+                break
+            time.sleep(0.2)
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+        if not bad:
+            return 0
+        if any(rc == 98 for _, rc in bad) and attempt < 2:   # EADDRINUSE reported by rank 0 (see main): new port, once more
+            print(f"[bench] rendezvous port {port} was taken; retrying on another port", file=sys.stderr)
+            continue
         print(f"[bench] ranks failed: {bad}", file=sys.stderr)
-    return max(abs(rc) for rc in rcs) if bad else 0
+        return max(abs(rc) for _, rc in bad)
+    return 3
 
 
 def main():
@@ -208,12 +264,16 @@ def main():
     ap.add_argument("--settle", type=int, default=10, help="throw-away conditioning steps (full loop body, on a copy of the latents) before the "
                     "W warm-up steps; 0 = none.  They absorb one-time costs that would otherwise land in a short timed region whatever W is: "
                     "first-call initialisation (~0.2-0.4 s) and the lazy load of the torch kernels of the NaN check (~30 ms); DESIGN.md section 4")
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (weak scaling: per-GPU work fixed as N grows); default = the workload's "
+                    "own batch (8 for the headline config)")
+    ap.add_argument("--global-batch", type=int, default=0, help="STRONG scaling: G clips in total, split over the --gpus N ranks (clip k -> rank "
+                    "k mod N as in Pipeline.__call__(shard=True)); valid at N = 1 too, e.g. --global-batch 32 --gpus 1 is the one-GPU number that "
+                    "BASELINE.json configs[2] (32 clips over 8 GPUs) is divided by")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU leg (0 = the whole affinity set of this process)")
     ap.add_argument("--cpu-batch", type=int, default=0, help="batch of the second CPU leg (0 = 8 if host memory allows, else 4 / 2 / none)")
     ap.add_argument("--no-nan-check", action="store_true", help="skip the per-step host-side NaN test of the loss (the reference loop has it)")
     ap.add_argument("--no-stage-times", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="run the U-Net as individual launches instead of the captured HIP graph")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (gloo backend only)")
@@ -235,21 +295,38 @@ def main():
         local = 0
     if world > 1:
         torch.cuda.set_device(local)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # backend "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
+        try:
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))   # backend "nccl" is RCCL on ROCm
+            else:
+                dist.init_process_group("gloo")
+        except Exception as e:                                   # noqa: BLE001
+            if "address already in use" in str(e).lower() or "EADDRINUSE" in str(e):
+                sys.exit(98)                                     # spawn_ranks retries on another port
+            raise
         if dist.get_world_size() != args.gpus:
             print(f"[bench] only {dist.get_world_size()} of {args.gpus} ranks joined", file=sys.stderr)
             sys.exit(3)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     wl = args.workload
-    B = args.batch if wl == "dps_inpainting" else WORKLOADS[wl][5]
+    strong = args.global_batch > 0
+    if strong:
+        if args.batch:
+            print("[bench] --batch (weak scaling) and --global-batch (strong scaling) are exclusive", file=sys.stderr)
+            sys.exit(3)
+        if args.global_batch < world:
+            print(f"[bench] --global-batch {args.global_batch} < {world} ranks: every rank needs at least one clip", file=sys.stderr)
+            sys.exit(3)
+        clip_ids = list(range(rank, args.global_batch, world))    # clip k -> rank k mod N (diffmusic_amd/parallel.py shard_indices)
+        G = args.global_batch
+    else:
+        Bw = args.batch or WORKLOADS[wl][5]
+        clip_ids = list(range(rank * Bw, (rank + 1) * Bw))
+        G = Bw * world
+    B = len(clip_ids)
     n_sched = WORKLOAD_STEPS.get(wl, N_STEPS)
-    pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device, wl)
-    if args.no_graph and hasattr(pipe.unet, "use_graph"):
-        pipe.unet.use_graph = False
+    pipe, op, measurement, latents, pe2, L = build_problem(B, rank, device, wl, clip_ids)
     ts = pipe.scheduler._timesteps_host
 
     def barrier():
@@ -312,10 +389,10 @@ def main():
     e1.record()
     barrier()
     tg = time.perf_counter()
-    gathered = parallel.gather_waveforms(audio, B * world)
+    gathered = parallel.gather_waveforms(audio, G)
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - tg)
-    assert gathered.shape == (B * world, L)
+    assert gathered.shape == (G, L)
     finite = finite and bool(torch.isfinite(gathered).all())
     final_decode_ms = e0.elapsed_time(e1)
 
@@ -367,30 +444,40 @@ def main():
 
     rc = 0
     if rank == 0:
-        steps_per_s = args.steps / wall * world                 # one step advances B clips on each of `world` GPUs
-        wl_text = {"dps_inpainting": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule, batch 8 per GPU (BASELINE.json configs[1])"}.get(
-            wl, f"{wl}: {WORKLOADS[wl][0]} + {WORKLOADS[wl][1]} {WORKLOADS[wl][4]}, 10 s @16 kHz, {n_sched}-step schedule, {WORKLOADS[wl][6]}")
+        # weak scaling (default): every rank advances its own B clips per step, so the job does `world` batch-B steps per loop pass
+        # and value = K / wall * world (steps of B clips).  Strong scaling (--global-batch G): one step advances all G clips of the
+        # job, value = K / wall (steps of G clips).  clip_steps_per_sec = G * K / wall in both conventions.
+        steps_per_s = args.steps / wall * (1 if strong else world)
+        clip_steps = G * args.steps / wall
+        base = {"dps_inpainting": "MusicLDM + DPS music_inpainting, 10 s @16 kHz, 200-step schedule",
+                }.get(wl, f"{wl}: {WORKLOADS[wl][0]} + {WORKLOADS[wl][1]} {WORKLOADS[wl][4]}, 10 s @16 kHz, {n_sched}-step schedule")
+        is_headline = wl == "dps_inpainting" and not strong and B == 8
+        wl_text = (f"{base}, {G} clips in total split over {world} GPU(s) ({B} on rank 0)" if strong else f"{base}, batch {B} per GPU") + \
+                  (" (BASELINE.json configs[1])" if is_headline else f" ({WORKLOADS[wl][6]})" if wl != "dps_inpainting" else " (configs[1] at another batch)")
+        unit = (f"steps/s (strong scaling: one step advances all {G} clips of the job; value = K / wall)" if strong else
+                f"steps/s (weak scaling: one step advances a batch of {B} clips on one GPU; value = K / wall x {world} GPU(s))")
         res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4) if finite else None,
-               "unit": f"steps/s (each step advances a batch of {B} clips per GPU)", "n_gpus": world, "steps": args.steps,
+               "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": wl_text, "global_batch": B * world, "clips_per_gpu": B,
-                          "clip_steps_per_sec": round(steps_per_s * B, 3), "parallelism": f"clip-sharded x{world} ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL'} world size {world}, no per-step collective)",
+               "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": wl_text, "global_batch": G, "clips_per_gpu": B,
+                          "clip_steps_per_sec": round(clip_steps, 3), "parallelism": f"clip-sharded x{world} ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL'} world size {world}, no per-step collective)",
                           "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_steps": nan_steps,
                           "nan_check_per_step": not args.no_nan_check,
                           "settle_steps": len(settle_ms), "settle_first3_ms": [round(v, 2) for v in settle_ms[:3]], "settle_last3_ms": [round(v, 2) for v in settle_ms[-3:]], "final_loss_clip0": float(loss.reshape(-1)[0]),
                           "cached_reference_transform": bool(getattr(op, "cache_reference", False)),
-                          "unet_hip_graph": bool(getattr(pipe.unet, "use_graph", False)),
                           "launched_by": "bench.py spawn" if os.environ.get("DMX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
                "after_loop": {"final_decode_ms": round(final_decode_ms, 3), "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
                               "gather_bytes_per_rank": int(audio.numel() * 4), "gather_world_size": world,
                               "collective": "all_gather of (clips_per_gpu, 160000) fp32 waveforms, once per call" if world > 1 else "none (single rank)"},
                "stage_ms": stages, "mel_path": mel_path, "roofline": roofline}
-        if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting":
-            threads = min(16, len(os.sched_getaffinity(0)))      # the GPU box's CPU share, not the host's core count
+        if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting" and not strong:
+            affinity = len(os.sched_getaffinity(0))
+            threads = affinity if args.cpu_threads <= 0 else min(args.cpu_threads, affinity)   # the whole CPU share of this process
             sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
-            print(f"[bench] timing the CPU oracle on {threads} threads (1 clip x 4 steps) ...", file=sys.stderr, flush=True)
-            sec1 = cpu_baseline(sd, threads, 1)
+            print(f"[bench] timing the CPU oracle on {threads} threads (host has {os.cpu_count()} logical CPUs, affinity {affinity}): "
+                  f"1 clip x (1 warm-up + 3 measured) steps ...", file=sys.stderr, flush=True)
+            sec1 = cpu_baseline(sd, threads, 1, 3)
             print(f"[bench] CPU oracle: {sec1:.2f} s per clip-step", file=sys.stderr, flush=True)
             cb = args.cpu_batch
             if cb == 0:
@@ -401,17 +488,20 @@ def main():
                     avail = 0.0
                 cb = next((b for b in (8, 4, 2) if 12.0 * b + 8.0 < 0.6 * avail), 1)      # ~12 GiB of autograd state per clip
             secb = None
+            n_b = 2
             if cb > 1:
-                print(f"[bench] timing the CPU oracle at batch {cb} (1 step) ...", file=sys.stderr, flush=True)
-                secb = cpu_baseline(sd, threads, cb)
+                print(f"[bench] timing the CPU oracle at batch {cb}: 1 warm-up + {n_b} measured steps ...", file=sys.stderr, flush=True)
+                secb = cpu_baseline(sd, threads, cb, n_b)
                 print(f"[bench] CPU oracle: {secb:.2f} s per batch-{cb} step", file=sys.stderr, flush=True)
-            v8 = 1.0 / (secb * (8.0 / cb)) if secb else 1.0 / (sec1 * B)
+            v8 = 1.0 / (secb * (8.0 / cb)) if secb else 1.0 / (sec1 * 8)
             res["cpu_baseline"] = {"value": round(v8, 6), "unit": "steps/s (batch-8 step)" if cb == 8 else "steps/s (batch-8 equivalent, extrapolated)",
-                                   "cores": threads, "kind": "port", "cpu_model": cpu_model_string(), "torch": torch.__version__,
+                                   "cores": threads, "host_logical_cpus": os.cpu_count(), "affinity_cpus": affinity, "threads_used": threads,
+                                   "kind": "port", "cpu_model": cpu_model_string(), "torch": torch.__version__,
                                    "batch1_seconds_per_step": round(sec1, 3), f"batch{cb}_seconds_per_step": round(secb, 3) if secb else None,
-                                   "gpu_over_cpu": round(steps_per_s / v8, 1),
-                                   "sample": f"oracle/ (fp32 eager torch + autograd, U-Net 2x fwd + guided step): 1 clip x 3 DPS steps after 1 warm-up "
-                                             f"({sec1:.2f} s/step)" + (f"; {cb} clips x 1 DPS step ({secb:.2f} s/step)" if secb else "")}
+                                   "batch1_x8_steps_per_sec": round(1.0 / (sec1 * 8), 6),
+                                   "gpu_over_cpu": round(clip_steps / (8 * v8), 1),
+                                   "sample": f"oracle/ (fp32 eager torch + autograd, U-Net 2x fwd + guided DPS step), warmed: 1 clip x 3 measured steps after 1 "
+                                             f"warm-up ({sec1:.2f} s/step)" + (f"; {cb} clips x {n_b} measured steps after 1 warm-up ({secb:.2f} s/step)" if secb else "")}
         print(json.dumps(res), flush=True)
         if not finite:
             print(f"[bench] non-finite loss / latents / waveforms (nan_steps={nan_steps}): value set to null", file=sys.stderr)

@@ -133,10 +133,14 @@ def lib():
                 continue               # optional symbols are checked by tests/test_abi.py
             fn = getattr(h, name)
             fn.restype, fn.argtypes = res, args
-        if h.dmx_abi_version() != 1:
-            raise RuntimeError("libdiffmusic_hip.so ABI version mismatch")
+        if h.dmx_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libdiffmusic_hip.so ABI version {h.dmx_abi_version()} != {ABI_VERSION} expected by this package: rebuild it "
+                               "(python -m diffmusic_amd.build --force)")
         _lib = h
     return _lib
+
+
+ABI_VERSION = 2          # include/diffmusic_hip.h DMX_ABI_VERSION
 
 
 def act_dtype():

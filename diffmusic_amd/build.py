@@ -83,7 +83,14 @@ def build_torch_ops(force=False, verbose=False):
     import torch
     lib = build_library(force=False, verbose=verbose)
     hdr = os.path.join(os.path.dirname(HERE), "include", "diffmusic_hip.h")
-    if not (force or _stale(TORCH_OPS_LIB, [TORCH_OPS_SRC, hdr, lib])):
+    # the op library is ABI-bound to the torch it was compiled against: a stamp holds that version, another torch rebuilds it
+    stamp = TORCH_OPS_LIB + ".torch_version"
+    try:
+        with open(stamp) as fh:
+            same_torch = fh.read().strip() == torch.__version__
+    except OSError:
+        same_torch = False
+    if not (force or not same_torch or _stale(TORCH_OPS_LIB, [TORCH_OPS_SRC, hdr, lib])):
         return TORCH_OPS_LIB
     tdir = os.path.dirname(torch.__file__)
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -97,6 +104,8 @@ def build_torch_ops(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building the torch op library failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+    with open(stamp, "w") as fh:
+        fh.write(torch.__version__ + "\n")
     return TORCH_OPS_LIB
 
 

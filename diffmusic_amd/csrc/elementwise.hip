@@ -517,20 +517,6 @@ __global__ __launch_bounds__(256) void softmax_act_kernel(const act_t* __restric
   }
 }
 
-// dS = P * (dP - sum_j dP_j P_j) * scale ; P bf16, dP fp32 -> dS bf16
-__global__ void softmax_bwd_kernel(const act_t* __restrict__ P, const float* __restrict__ dP, act_t* __restrict__ dS,
-                                   int N, long long ld, float scale) {
-  __shared__ float sh[16];
-  const long long row = blockIdx.x;
-  const act_t* p = P + row * ld;
-  const float* d = dP + row * ld;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) acc += a2f(p[i]) * d[i];
-  acc = block_sum(acc, sh);
-  act_t* o = dS + row * ld;
-  for (int i = threadIdx.x; i < N; i += blockDim.x) o[i] = f2a(a2f(p[i]) * (d[i] - acc) * scale);
-}
-
 // ------------------------------------------------------------------------------ GEGLU: (rows, 2I) -> (rows, I)
 __global__ void geglu_kernel(const act_t* __restrict__ x, act_t* __restrict__ y, long long rows, int I) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1000,11 +986,6 @@ int dmx_softmax_act(const act_t* S, act_t* P, const float* colbias, long long ro
     hipLaunchKernelGGL(softmax_act_kernel<64>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, P, colbias, rows, N, ldp, rpb);
   else
     hipLaunchKernelGGL(softmax_act_kernel<256>, dim3((unsigned)rows), dim3(256), 0, st, S, P, colbias, rows, N, ldp, rpb);
-  return CHECK_LAUNCH();
-}
-int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(N >= 1024 ? 256 : 64), 0, st, P, dP, dS, N, ld, scale);
   return CHECK_LAUNCH();
 }
 int dmx_geglu(const act_t* x, act_t* y, long long rows, int I, hipStream_t st) {

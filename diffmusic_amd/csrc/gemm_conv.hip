@@ -578,9 +578,8 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   }
 }
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
-  static const bool legacy = getenv("DMX_GEMM_LEGACY") != nullptr;
-  const bool gl = !legacy && glds_ok(d);
-  if (d.flags & EPI_SOFTBWD) return gl ? launch_by_cfg(1, d, stream) : DMX_ERR_SHAPE;
+  const bool gl = glds_ok(d);
+  if (d.flags & EPI_SOFTBWD) return gl ? launch_by_cfg(1, d, stream) : DMX_ERR_SHAPE;   // (its one caller checks the span up front: vae.hip)
   if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
     static int ovN[8], ovC[8], nov = -1;

@@ -204,6 +204,13 @@ struct HifiGan : Model {
             pa[k] = &da[k]; pb[k] = &db[k];
           }
           if (dry) continue;
+          // the tape of these steps holds sign bits only (no ha tensor exists): the unfused two-launch fallback of conv_pair_run
+          // would run stage a with C2 == nullptr -- refuse instead of falling back silently
+          for (int k = 0; k < nk; ++k)
+            if (!dmx_conv_pair_eligible(&da[k], db[k])) {
+              dmx_set_error("hifigan: resblock step %d was planned as fused but the pair kernel refuses it", idx(s, k, d));
+              return DMX_ERR_STATE;
+            }
           if (d < nd - 1) RUN(dmx_conv_pair_group_launch(nk, pa, pb, st));
           else for (int k = 0; k < nk; ++k) RUN(conv_pair_run(da[k], db[k], st));
         }

@@ -17,8 +17,6 @@ int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long ro
                     int rows_per_bias, hipStream_t st);
 int dmx_softmax_act(const act_t* S, act_t* P, const float* colbias, long long rows, int N, long long ldp, int rows_per_bias,
                     hipStream_t st);
-int dmx_softmax_bwd(const act_t* P, const float* dP, act_t* dS, long long rows, int N, long long ld, float scale,
-                    hipStream_t st);
 int dmx_rowdot(const act_t* a, const act_t* b, float* out, long long rows, int C, long long lda, long long ldb, hipStream_t st);
 int dmx_geglu(const act_t* x, act_t* y, long long rows, int I, hipStream_t st);
 int dmx_silu(const act_t* x, act_t* y, long long n, hipStream_t st);

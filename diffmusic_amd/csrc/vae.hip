@@ -203,6 +203,9 @@ struct VaeDecoder : Model {
     {  // attention backward
       const int N = (int)P, C = Cmid;
       if (N & 7) { dmx_set_error("vae attention backward needs h*w %% 8 == 0"); return DMX_ERR_SHAPE; }
+      // the softmax backward exists only as the fused epilogue of the dP GEMM on the LDS-DMA 256x256 tile (32-bit buffer offsets):
+      // say so here instead of failing inside the launch (B <= 64 keeps every supported shape below the limit)
+      if ((long long)B * N * C >= (1ll << 29)) { dmx_set_error("vae attention backward: B*h*w*C >= 2^29 elements unsupported"); return DMX_ERR_SHAPE; }
       const float scale = 1.0f / sqrtf((float)C);
       act_t* gx = A.bf((size_t)B * N * C);
       const size_t mk = A.mark();

@@ -8,6 +8,8 @@
 // Callers on the reference side are its three protocols (Scheduler.step, Pipeline.__call__, BaseOperator); the reference
 // lines each op replaces are cited at the C-ABI declarations.
 #include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // torch-ROCm tensors report DeviceType::CUDA: the guard / stream types that accept it
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -15,7 +17,13 @@
 
 namespace {
 
-inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+// every op makes its first tensor's device current for its own duration, so the outputs are allocated there and the launch goes to
+// THAT device's current stream (a tensor on a non-current device must not be enqueued on the current device's stream)
+#define DMX_DEVICE_OF(t) const c10::hip::HIPGuardMasqueradingAsCUDA dmx_guard_((t).device())
+inline void* cur_stream() { return (void*)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+inline void same_numel(const at::Tensor& a, const at::Tensor& b, const char* what) {
+  TORCH_CHECK(a.numel() == b.numel() && a.device() == b.device(), what, ": size / device mismatch");
+}
 
 inline void ok(int rc, const char* what) {
   TORCH_CHECK(rc == 0, "diffmusic_hip::", what, " failed with code ", rc, ": ", dmx_last_error());
@@ -33,7 +41,8 @@ inline const float* fp(const std::optional<at::Tensor>& t) { return t.has_value(
 // ---- scheduler arithmetic (scheduling_{ddim,dps,mpgd,dsg,diffmusic}.py step bodies; pipeline_musicldm.py:706-708)
 at::Tensor sched_pred_x0(const at::Tensor& x, const at::Tensor& eps, double alpha_t) {
   f32_cuda(x, "x"); f32_cuda(eps, "eps");
-  TORCH_CHECK(x.numel() == eps.numel(), "x / eps size mismatch");
+  same_numel(x, eps, "sched_pred_x0(x, eps)");
+  DMX_DEVICE_OF(x);
   at::Tensor x0 = at::empty_like(x);
   ok(dmx_sched_pred_x0(x.data_ptr<float>(), eps.data_ptr<float>(), x0.data_ptr<float>(), x.numel(), (float)alpha_t, cur_stream()), "sched_pred_x0");
   return x0;
@@ -41,33 +50,42 @@ at::Tensor sched_pred_x0(const at::Tensor& x, const at::Tensor& eps, double alph
 at::Tensor cfg_combine(const at::Tensor& eps2, double scale) {
   f32_cuda(eps2, "eps2");
   TORCH_CHECK(eps2.dim() >= 1 && eps2.size(0) % 2 == 0, "eps2 must hold the [uncond | text] halves of the CFG batch");
+  DMX_DEVICE_OF(eps2);
   auto sizes = eps2.sizes().vec();
   sizes[0] /= 2;
   at::Tensor out = at::empty(sizes, eps2.options());
   ok(dmx_sched_cfg_combine(eps2.data_ptr<float>(), out.data_ptr<float>(), out.numel(), (float)scale, cur_stream()), "cfg_combine");
   return out;
 }
-std::tuple<at::Tensor, at::Tensor> sched_update(int64_t mode, const at::Tensor& x, const at::Tensor& eps, const at::Tensor& x0,
+// returns (prev_sample, x0_updated): the second is MPGD's guided x0 (scheduling_mpgd.py:202) and None for every other mode (no output
+// aliases an input: the schema is a plain functional op)
+std::tuple<at::Tensor, std::optional<at::Tensor>> sched_update(int64_t mode, const at::Tensor& x, const at::Tensor& eps, const at::Tensor& x0,
                                                 const std::optional<at::Tensor>& g0, const std::optional<at::Tensor>& inv_scale,
                                                 const std::optional<at::Tensor>& noise, double alpha_t, double alpha_prev, double sigma,
                                                 double rate, double eps_small, bool global_norm) {
   f32_cuda(x, "x"); f32_cuda(eps, "eps"); f32_cuda(x0, "x0");
-  if (g0) f32_cuda(*g0, "g0");
-  if (inv_scale) f32_cuda(*inv_scale, "inv_scale");
-  if (noise) f32_cuda(*noise, "noise");
+  TORCH_CHECK(x.dim() >= 1 && x.size(0) >= 1, "x must have a batch dimension");
+  same_numel(x, eps, "sched_update(x, eps)"); same_numel(x, x0, "sched_update(x, x0)");
   const int B = (int)x.size(0);
   const int n = (int)(x.numel() / B);
+  if (g0) { f32_cuda(*g0, "g0"); same_numel(x, *g0, "sched_update(x, g0)"); }
+  if (inv_scale) { f32_cuda(*inv_scale, "inv_scale"); TORCH_CHECK(inv_scale->numel() == B && inv_scale->device() == x.device(), "inv_scale must hold one value per clip"); }
+  if (noise) { f32_cuda(*noise, "noise"); same_numel(x, *noise, "sched_update(x, noise)"); }
+  TORCH_CHECK(mode == DMX_SCHED_DDIM || (g0 && inv_scale), "guided modes need g0 and inv_scale");
+  DMX_DEVICE_OF(x);
   at::Tensor prev = at::empty_like(x);
-  at::Tensor x0_out = mode == DMX_SCHED_MPGD ? at::empty_like(x) : x0;
+  std::optional<at::Tensor> x0_out;
+  if (mode == DMX_SCHED_MPGD) x0_out = at::empty_like(x);
   ok(dmx_sched_step((int)mode, x.data_ptr<float>(), eps.data_ptr<float>(), x0.data_ptr<float>(), fp(g0), fp(inv_scale), fp(noise),
-                    prev.data_ptr<float>(), mode == DMX_SCHED_MPGD ? x0_out.data_ptr<float>() : nullptr, nullptr, B, n, (float)alpha_t,
+                    prev.data_ptr<float>(), x0_out ? x0_out->data_ptr<float>() : nullptr, nullptr, B, n, (float)alpha_t,
                     (float)alpha_prev, (float)sigma, (float)rate, (float)eps_small, global_norm ? 1 : 0, cur_stream()), "sched_update");
   return {prev, x0_out};
 }
 at::Tensor randn_philox(at::IntArrayRef shape, at::IntArrayRef seeds, int64_t offset, at::Device device) {
   TORCH_CHECK(!shape.empty() && (int64_t)seeds.size() == shape[0] && shape[0] <= 64, "need one seed per clip (batch <= 64)");
+  TORCH_CHECK(device.is_cuda(), "randn_philox draws on the GPU");
+  const c10::hip::HIPGuardMasqueradingAsCUDA guard(device);
   at::Tensor out = at::empty(shape, at::TensorOptions().dtype(at::kFloat).device(device));
-  TORCH_CHECK(out.is_cuda(), "randn_philox draws on the GPU");
   std::vector<unsigned long long> s(seeds.begin(), seeds.end());
   ok(dmx_randn_philox(out.data_ptr<float>(), (int)shape[0], out.numel() / shape[0], s.data(), (unsigned long long)offset, cur_stream()), "randn_philox");
   return out;
@@ -76,6 +94,7 @@ at::Tensor randn_philox(at::IntArrayRef shape, at::IntArrayRef seeds, int64_t of
 // ---- measurement operators (operator.py) and the loss (scheduling_dps.py:211)
 at::Tensor mask_mul(const at::Tensor& x, const std::optional<at::Tensor>& mask, int64_t L, int64_t Ly) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2 && x.stride(1) == 1, "x must be (B, >= L) fp32 on the GPU");
+  DMX_DEVICE_OF(x);
   if (mask) f32_cuda(*mask, "mask");
   at::Tensor y = at::empty({x.size(0), Ly}, x.options());
   ok(dmx_mask_apply(x.data_ptr<float>(), x.stride(0), fp(mask), y.data_ptr<float>(), Ly, (int)x.size(0), (int)L, (int)Ly, cur_stream()), "mask_mul");
@@ -83,9 +102,10 @@ at::Tensor mask_mul(const at::Tensor& x, const std::optional<at::Tensor>& mask, 
 }
 std::tuple<at::Tensor, at::Tensor> l2norm(const at::Tensor& ref, const at::Tensor& pred, double gscale) {
   f32_cuda(ref, "ref"); f32_cuda(pred, "pred");
+  DMX_DEVICE_OF(pred);
   const int B = (int)pred.size(0);
   const long long n = pred.numel() / B;
-  TORCH_CHECK(ref.numel() == n || ref.numel() == n * B, "ref must match pred or broadcast over the batch");
+  TORCH_CHECK((ref.numel() == n || ref.numel() == n * B) && ref.device() == pred.device(), "ref must match pred or broadcast over the batch");
   at::Tensor loss = at::empty({B}, pred.options()), dpred = at::empty_like(pred);
   ok(dmx_l2_loss(ref.data_ptr<float>(), ref.numel() == n && B > 1 ? 0 : n, pred.data_ptr<float>(), loss.data_ptr<float>(), dpred.data_ptr<float>(),
                  B, n, (float)gscale, cur_stream()), "l2norm");
@@ -93,6 +113,7 @@ std::tuple<at::Tensor, at::Tensor> l2norm(const at::Tensor& ref, const at::Tenso
 }
 at::Tensor resample_fwd(const at::Tensor& x, const at::Tensor& h, int64_t Lin, int64_t Lout, int64_t orig, int64_t new_, int64_t off) {
   TORCH_CHECK(x.is_cuda() && x.scalar_type() == at::kFloat && x.dim() == 2 && x.stride(1) == 1, "x must be (B, >= Lin) fp32 on the GPU");
+  DMX_DEVICE_OF(x);
   f32_cuda(h, "h");
   at::Tensor y = at::empty({x.size(0), Lout}, x.options());
   ok(dmx_fir_fwd(x.data_ptr<float>(), x.stride(0), h.data_ptr<float>(), y.data_ptr<float>(), Lout, (int)x.size(0), (int)Lin, (int)Lout,
@@ -102,6 +123,7 @@ at::Tensor resample_fwd(const at::Tensor& x, const at::Tensor& h, int64_t Lin, i
 at::Tensor resample_bwd(const at::Tensor& dy, const at::Tensor& h, const std::optional<at::Tensor>& h_rev, int64_t Lin, int64_t Lfull,
                         int64_t orig, int64_t new_, int64_t off) {
   f32_cuda(dy, "dy"); f32_cuda(h, "h");
+  DMX_DEVICE_OF(dy);
   at::Tensor d = at::zeros({dy.size(0), Lfull}, dy.options());
   ok(dmx_fir_bwd(dy.data_ptr<float>(), dy.size(1), h.data_ptr<float>(), fp(h_rev), d.data_ptr<float>(), Lfull, (int)dy.size(0), (int)Lin,
                  (int)dy.size(1), (int)h.size(-1), (int)orig, (int)new_, (int)off, cur_stream()), "resample_bwd");
@@ -110,6 +132,7 @@ at::Tensor resample_bwd(const at::Tensor& dy, const at::Tensor& h, const std::op
 at::Tensor logmel_fwd(int64_t audio, const at::Tensor& wav, const at::Tensor& state, int64_t L, bool power2, bool to_db, double lo, double hi) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   TORCH_CHECK(wav.is_cuda() && wav.scalar_type() == at::kFloat && wav.dim() == 2 && wav.stride(1) == 1, "wav must be (B, >= L) fp32 on the GPU");
+  DMX_DEVICE_OF(wav);
   TORCH_CHECK(state.is_cuda() && (size_t)state.nbytes() >= dmx_audio_state_bytes(a, (int)wav.size(0), (int)L), "state buffer too small");
   at::Tensor mel = at::empty({wav.size(0), dmx_audio_num_frames(a, (int)L), 64}, wav.options());
   ok(dmx_audio_transform_fwd(a, wav.data_ptr<float>(), wav.stride(0), mel.data_ptr<float>(), state.data_ptr(), (int)wav.size(0), (int)L,
@@ -119,6 +142,7 @@ at::Tensor logmel_fwd(int64_t audio, const at::Tensor& wav, const at::Tensor& st
 at::Tensor logmel_bwd(int64_t audio, const at::Tensor& dmel, const at::Tensor& state, int64_t L, bool power2, bool to_db, double lo, double hi) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   f32_cuda(dmel, "dmel");
+  DMX_DEVICE_OF(dmel);
   at::Tensor dwav = at::empty({dmel.size(0), L}, dmel.options());
   ok(dmx_audio_transform_bwd(a, dmel.data_ptr<float>(), dwav.data_ptr<float>(), L, state.data_ptr(), (int)dmel.size(0), (int)L, power2, to_db,
                              (float)lo, (float)hi, 0, cur_stream()), "logmel_bwd");
@@ -127,6 +151,7 @@ at::Tensor logmel_bwd(int64_t audio, const at::Tensor& dmel, const at::Tensor& s
 at::Tensor stft_mag_fwd(int64_t audio, const at::Tensor& wav, const at::Tensor& state, int64_t L) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   TORCH_CHECK(wav.is_cuda() && wav.scalar_type() == at::kFloat && wav.dim() == 2 && wav.stride(1) == 1, "wav must be (B, >= L) fp32 on the GPU");
+  DMX_DEVICE_OF(wav);
   const int T = dmx_audio_num_frames(a, (int)L);
   TORCH_CHECK((size_t)state.nbytes() >= dmx_audio_state_bytes(a, (int)wav.size(0), (int)L), "state buffer too small");
   at::Tensor mag = at::empty({wav.size(0), dmx_audio_num_bins(a), T}, wav.options());
@@ -136,6 +161,7 @@ at::Tensor stft_mag_fwd(int64_t audio, const at::Tensor& wav, const at::Tensor& 
 at::Tensor stft_mag_bwd(int64_t audio, const at::Tensor& dmag, const at::Tensor& state, int64_t L, int64_t Lfull) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   f32_cuda(dmag, "dmag");
+  DMX_DEVICE_OF(dmag);
   at::Tensor dwav = at::zeros({dmag.size(0), Lfull}, dmag.options());
   ok(dmx_audio_stft_mag_bwd(a, dmag.data_ptr<float>(), dwav.data_ptr<float>(), Lfull, state.data_ptr(), (int)dmag.size(0), (int)L, 0, cur_stream()), "stft_mag_bwd");
   return dwav;
@@ -143,6 +169,7 @@ at::Tensor stft_mag_bwd(int64_t audio, const at::Tensor& dmag, const at::Tensor&
 at::Tensor melscale_fwd(int64_t audio, const at::Tensor& mag, double lo, double hi) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   f32_cuda(mag, "mag");
+  DMX_DEVICE_OF(mag);
   at::Tensor mel = at::empty({mag.size(0), mag.size(2), 64}, mag.options());
   ok(dmx_audio_melscale(a, mag.data_ptr<float>(), mel.data_ptr<float>(), (int)mag.size(0), (int)mag.size(2), (float)lo, (float)hi, cur_stream()), "melscale_fwd");
   return mel;
@@ -151,28 +178,59 @@ at::Tensor melscale_fwd(int64_t audio, const at::Tensor& mag, double lo, double 
 // ---- networks (handles from dmx_*_create; workspaces are caller-owned byte tensors sized by *_workspace_bytes)
 at::Tensor unet_fwd(int64_t model, const at::Tensor& x, const at::Tensor& t, const std::optional<at::Tensor>& class_labels, at::Tensor ws) {
   f32_cuda(x, "x"); f32_cuda(t, "t");
+  DMX_DEVICE_OF(x);
   if (class_labels) f32_cuda(*class_labels, "class_labels");
   at::Tensor eps = at::empty_like(x);
   ok(dmx_unet_fwd(reinterpret_cast<dmx_model*>(model), x.data_ptr<float>(), t.data_ptr<float>(), fp(class_labels), eps.data_ptr<float>(),
                   (int)x.size(0), (int)x.size(2), (int)x.size(3), ws.data_ptr(), ws.nbytes(), cur_stream()), "unet_fwd");
   return eps;
 }
-at::Tensor vae_dec_fwd(int64_t model, const at::Tensor& z, double z_scale, bool keep_state, at::Tensor ws) {
-  f32_cuda(z, "z");
-  const int B = (int)z.size(0), h = (int)z.size(2), w = (int)z.size(3);
-  at::Tensor mel = at::empty({B, 4 * h, 4 * w}, z.options().dtype(dmx_act_dtype() == 1 ? at::kHalf : at::kBFloat16));
-  ok(dmx_vae_decode_fwd(reinterpret_cast<dmx_model*>(model), z.data_ptr<float>(), (float)z_scale, (uint16_t*)mel.data_ptr(), nullptr, B, h, w,
-                        keep_state, ws.data_ptr(), ws.nbytes(), cur_stream()), "vae_dec_fwd");
-  return mel;
+// AudioLDM2UNet2DConditionModel call (plpeline_audioldm2.py:1147-1154): GPT-2 states c0 (B, n0, d0), T5 states c1 (B, n1, d1) + additive key bias
+at::Tensor unet_fwd_ctx(int64_t model, const at::Tensor& x, const at::Tensor& t, const std::optional<at::Tensor>& class_labels,
+                        const at::Tensor& c0, const at::Tensor& c1, const at::Tensor& bias1, at::Tensor ws) {
+  f32_cuda(x, "x"); f32_cuda(t, "t"); f32_cuda(c0, "encoder_hidden_states"); f32_cuda(c1, "encoder_hidden_states_1"); f32_cuda(bias1, "bias1");
+  if (class_labels) f32_cuda(*class_labels, "class_labels");
+  TORCH_CHECK(c0.dim() == 3 && c1.dim() == 3 && c0.size(0) == x.size(0) && c1.size(0) == x.size(0) && bias1.numel() == c1.size(0) * c1.size(1),
+              "context tensors must be (B, tokens, dim) with one additive bias per T5 token");
+  DMX_DEVICE_OF(x);
+  at::Tensor eps = at::empty_like(x);
+  ok(dmx_unet_fwd_ctx(reinterpret_cast<dmx_model*>(model), x.data_ptr<float>(), t.data_ptr<float>(), fp(class_labels), c0.data_ptr<float>(),
+                      (int)c0.size(1), c1.data_ptr<float>(), (int)c1.size(1), bias1.data_ptr<float>(), eps.data_ptr<float>(), (int)x.size(0),
+                      (int)x.size(2), (int)x.size(3), ws.data_ptr(), ws.nbytes(), cur_stream()), "unet_fwd_ctx");
+  return eps;
 }
-at::Tensor vae_dec_bwd(int64_t model, const at::Tensor& dmel, double z_scale, int64_t latent_channels) {
+// returns (mel 16-bit, mel fp32 or None): `vae.decode(z).sample` (scheduling_dps.py:195-197)
+std::tuple<at::Tensor, std::optional<at::Tensor>> vae_dec_fwd(int64_t model, const at::Tensor& z, double z_scale, bool keep_state, bool want_f32,
+                                                              int64_t scale_factor, at::Tensor ws) {
+  f32_cuda(z, "z");
+  DMX_DEVICE_OF(z);
+  const int B = (int)z.size(0), h = (int)z.size(2), w = (int)z.size(3);
+  at::Tensor mel = at::empty({B, scale_factor * h, scale_factor * w}, z.options().dtype(dmx_act_dtype() == 1 ? at::kHalf : at::kBFloat16));
+  std::optional<at::Tensor> mel32;
+  if (want_f32) mel32 = at::empty({B, scale_factor * h, scale_factor * w}, z.options());
+  ok(dmx_vae_decode_fwd(reinterpret_cast<dmx_model*>(model), z.data_ptr<float>(), (float)z_scale, (uint16_t*)mel.data_ptr(),
+                        mel32 ? mel32->data_ptr<float>() : nullptr, B, h, w, keep_state, ws.data_ptr(), ws.nbytes(), cur_stream()), "vae_dec_fwd");
+  return {mel, mel32};
+}
+// per-clip rescale of the waveform gradient before the 16-bit backward sweep (max |g| -> target), IN PLACE; returns the factors that undo it
+at::Tensor grad_normalize_(at::Tensor dwav, double target) {
+  f32_cuda(dwav, "dwav");
+  TORCH_CHECK(dwav.dim() == 2, "dwav must be (B, samples)");
+  DMX_DEVICE_OF(dwav);
+  at::Tensor inv = at::empty({dwav.size(0)}, dwav.options());
+  ok(dmx_grad_normalize(dwav.data_ptr<float>(), inv.data_ptr<float>(), (int)dwav.size(0), dwav.size(1), (float)target, cur_stream()), "grad_normalize");
+  return inv;
+}
+at::Tensor vae_dec_bwd(int64_t model, const at::Tensor& dmel, double z_scale, int64_t latent_channels, int64_t scale_factor) {
   act_cuda(dmel, "dmel");
-  at::Tensor dz = at::empty({dmel.size(0), latent_channels, dmel.size(1) / 4, dmel.size(2) / 4}, dmel.options().dtype(at::kFloat));
+  DMX_DEVICE_OF(dmel);
+  at::Tensor dz = at::empty({dmel.size(0), latent_channels, dmel.size(1) / scale_factor, dmel.size(2) / scale_factor}, dmel.options().dtype(at::kFloat));
   ok(dmx_vae_decode_bwd(reinterpret_cast<dmx_model*>(model), (const uint16_t*)dmel.data_ptr(), (float)z_scale, dz.data_ptr<float>(), cur_stream()), "vae_dec_bwd");
   return dz;
 }
 at::Tensor hifigan_fwd(int64_t model, const at::Tensor& mel, at::Tensor ws) {
   act_cuda(mel, "mel");
+  DMX_DEVICE_OF(mel);
   dmx_model* m = reinterpret_cast<dmx_model*>(model);
   const int B = (int)mel.size(0), T = (int)mel.size(1);
   at::Tensor wav = at::empty({B, dmx_hifigan_out_len(m, T)}, mel.options().dtype(at::kFloat));
@@ -181,6 +239,7 @@ at::Tensor hifigan_fwd(int64_t model, const at::Tensor& mel, at::Tensor ws) {
 }
 at::Tensor hifigan_bwd(int64_t model, const at::Tensor& dwav, int64_t frames, int64_t model_in_dim) {
   f32_cuda(dwav, "dwav");
+  DMX_DEVICE_OF(dwav);
   at::Tensor dmel = at::empty({dwav.size(0), frames, model_in_dim}, dwav.options().dtype(dmx_act_dtype() == 1 ? at::kHalf : at::kBFloat16));
   ok(dmx_hifigan_bwd(reinterpret_cast<dmx_model*>(model), dwav.data_ptr<float>(), (uint16_t*)dmel.data_ptr(), cur_stream()), "hifigan_bwd");
   return dmel;
@@ -192,7 +251,7 @@ TORCH_LIBRARY(diffmusic_hip, m) {
   m.def("sched_pred_x0(Tensor x, Tensor eps, float alpha_t) -> Tensor", &sched_pred_x0);
   m.def("cfg_combine(Tensor eps2, float scale) -> Tensor", &cfg_combine);
   m.def("sched_update(int mode, Tensor x, Tensor eps, Tensor x0, Tensor? g0, Tensor? inv_scale, Tensor? noise, float alpha_t, float alpha_prev, "
-        "float sigma, float rate, float eps_small, bool global_norm) -> (Tensor, Tensor)", &sched_update);
+        "float sigma, float rate, float eps_small, bool global_norm) -> (Tensor, Tensor?)", &sched_update);
   m.def("randn_philox(int[] shape, int[] seeds, int offset, Device device) -> Tensor", &randn_philox);
   m.def("mask_mul(Tensor x, Tensor? mask, int L, int Ly) -> Tensor", &mask_mul);
   m.def("l2norm(Tensor ref, Tensor pred, float gscale) -> (Tensor, Tensor)", &l2norm);
@@ -204,8 +263,10 @@ TORCH_LIBRARY(diffmusic_hip, m) {
   m.def("stft_mag_bwd(int audio, Tensor dmag, Tensor state, int L, int Lfull) -> Tensor", &stft_mag_bwd);
   m.def("melscale_fwd(int audio, Tensor mag, float lo, float hi) -> Tensor", &melscale_fwd);
   m.def("unet_fwd(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor ws) -> Tensor", &unet_fwd);
-  m.def("vae_dec_fwd(int model, Tensor z, float z_scale, bool keep_state, Tensor ws) -> Tensor", &vae_dec_fwd);
-  m.def("vae_dec_bwd(int model, Tensor dmel, float z_scale, int latent_channels) -> Tensor", &vae_dec_bwd);
+  m.def("unet_fwd_ctx(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor c0, Tensor c1, Tensor bias1, Tensor ws) -> Tensor", &unet_fwd_ctx);
+  m.def("vae_dec_fwd(int model, Tensor z, float z_scale, bool keep_state, bool want_f32, int scale_factor, Tensor ws) -> (Tensor, Tensor?)", &vae_dec_fwd);
+  m.def("vae_dec_bwd(int model, Tensor dmel, float z_scale, int latent_channels, int scale_factor) -> Tensor", &vae_dec_bwd);
+  m.def("grad_normalize_(Tensor(a!) dwav, float target) -> Tensor", &grad_normalize_);
   m.def("hifigan_fwd(int model, Tensor mel, Tensor ws) -> Tensor", &hifigan_fwd);
   m.def("hifigan_bwd(int model, Tensor dwav, int frames, int model_in_dim) -> Tensor", &hifigan_bwd);
 }

@@ -1,10 +1,12 @@
 """Python handles over the native network executors (HiFi-GAN, VAE decoder, U-Net).
 
 Only plumbing lives here: device buffers come from torch (caching allocator), launches go to the
-C ABI on torch's current HIP stream."""
+C ABI on torch's current HIP stream -- through the PyTorch custom ops `torch.ops.diffmusic_hip.*`
+(csrc_torch/torch_ops.cpp; default) or through ctypes (DMX_TORCH_OPS=0), the same `extern "C"` launchers either way."""
 import ctypes as C
 import torch
 from . import _lib as L
+from . import ops
 from .weights import synth_state_dict
 
 HIFIGAN_DEFAULT = dict(model_in_dim=64, upsample_initial_channel=1024, upsample_rates=[5, 4, 2, 2, 2],
@@ -131,14 +133,18 @@ class HifiGanEngine(_Engine):
         B, T, _ = mel.shape
         lib = L.lib()
         ws = self._workspace(("h", B, T), lib.dmx_hifigan_workspace_bytes(self._h, B, T))
+        self._shape = (B, T)
+        if ops.enabled():
+            return ops.hip.hifigan_fwd(self._h.value, mel, ws)
         wav = torch.empty(B, self.out_len(T), dtype=torch.float32, device=mel.device)
         L.check(lib.dmx_hifigan_fwd(self._h, _ptr(mel), _ptr(wav), B, T, _ptr(ws), ws.numel(), _stream()), "hifigan_fwd")
-        self._shape = (B, T)
         return wav
 
     def backward(self, dwav):
         B, T = self._shape
         assert dwav.dtype == torch.float32 and dwav.is_contiguous()
+        if ops.enabled():
+            return ops.hip.hifigan_bwd(self._h.value, dwav, T, self.cfg["model_in_dim"])
         dmel = torch.empty(B, T, self.cfg["model_in_dim"], dtype=L.act_dtype(), device=dwav.device)
         L.check(L.lib().dmx_hifigan_bwd(self._h, _ptr(dwav), _ptr(dmel), _stream()), "hifigan_bwd")
         return dmel
@@ -178,16 +184,21 @@ class VaeDecoderEngine(_Engine):
         lib = L.lib()
         ws = self._workspace(("v", B, h, w), lib.dmx_vae_workspace_bytes(self._h, B, h, w))
         s = self.scale_factor
+        self._shape = (B, h, w)
+        if ops.enabled():
+            mel, mel32 = ops.hip.vae_dec_fwd(self._h.value, z, float(z_scale), bool(keep_state), bool(want_f32), s, ws)
+            return (mel, mel32) if want_f32 else mel
         mel = torch.empty(B, h * s, w * s, dtype=L.act_dtype(), device=z.device)
         mel32 = torch.empty(B, h * s, w * s, dtype=torch.float32, device=z.device) if want_f32 else None
         L.check(lib.dmx_vae_decode_fwd(self._h, _ptr(z), float(z_scale), _ptr(mel), _ptr(mel32), B, h, w, int(keep_state),
                                        _ptr(ws), ws.numel(), _stream()), "vae_decode_fwd")
-        self._shape = (B, h, w)
         return (mel, mel32) if want_f32 else mel
 
     def backward(self, dmel, z_scale=1.0):
         B, h, w = self._shape
         assert dmel.dtype == L.act_dtype() and dmel.is_contiguous()
+        if ops.enabled():
+            return ops.hip.vae_dec_bwd(self._h.value, dmel, float(z_scale), self.cfg["latent_channels"], self.scale_factor)
         dz = torch.empty(B, self.cfg["latent_channels"], h, w, dtype=torch.float32, device=dmel.device)
         L.check(L.lib().dmx_vae_decode_bwd(self._h, _ptr(dmel), float(z_scale), _ptr(dz), _stream()), "vae_decode_bwd")
         return dz
@@ -227,9 +238,12 @@ class UNetEngine(_Engine):
         if class_labels is not None:
             class_labels = class_labels.to(device=dev, dtype=torch.float32).contiguous()
         lib = L.lib()
-        eps = torch.empty(B, self.cfg["out_channels"], h, w, dtype=torch.float32, device=dev)
+        use_ops = ops.enabled() and self.cfg["out_channels"] == self.cfg["in_channels"]
+        eps = None if use_ops else torch.empty(B, self.cfg["out_channels"], h, w, dtype=torch.float32, device=dev)
         if self._n_ctx == 0:
             ws = self._workspace(("u", B, h, w), lib.dmx_unet_workspace_bytes(self._h, B, h, w))
+            if use_ops:
+                return ops.hip.unet_fwd(self._h.value, x, t, class_labels, ws)
             L.check(lib.dmx_unet_fwd(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(eps), B, h, w, _ptr(ws), ws.numel(),
                                      _stream()), "unet_fwd")
             return eps
@@ -245,6 +259,8 @@ class UNetEngine(_Engine):
         bias1 = ((1.0 - m1) * -10000.0).contiguous()
         n0, n1 = c0.shape[1], c1.shape[1]
         ws = self._workspace(("u", B, h, w, n0, n1), lib.dmx_unet_workspace_bytes_ctx(self._h, B, h, w, n0, n1))
+        if use_ops:
+            return ops.hip.unet_fwd_ctx(self._h.value, x, t, class_labels, c0, c1, bias1, ws)
         L.check(lib.dmx_unet_fwd_ctx(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(c0), n0, _ptr(c1), n1, _ptr(bias1), _ptr(eps),
                                      B, h, w, _ptr(ws), ws.numel(), _stream()), "unet_fwd_ctx")
         return eps

@@ -5,10 +5,14 @@ compiled from csrc_torch/torch_ops.cpp into lib/libdiffmusic_torch_ops.so and lo
     prev, x0 = ops.hip.sched_update(1, x, eps, x0, g0, inv_scale, None, a_t, a_p, sigma, rate, 1e-8, False)
 
 The facades (`Scheduler.step`, `Pipeline.__call__`, the operators) may call either this layer or the ctypes binding of the
-same entry points (`_lib.py`); both end in the same `extern "C"` launchers on torch's current HIP stream.  The scheduler
-arithmetic of the facade (x0 prediction, CFG combine, fused update) goes through this layer by default; DMX_TORCH_OPS=0
-switches those three calls to the ctypes binding.  No CPU fallback: a missing library raises."""
+same entry points (`_lib.py`); both end in the same `extern "C"` launchers on torch's current HIP stream.  By default the
+facade's per-step device work goes through this layer: the network stages (U-Net, VAE decode forward / backward, HiFi-GAN
+forward / backward: diffmusic_amd/engine.py), the gradient rescale and the scheduler arithmetic (x0 prediction, CFG combine,
+fused update).  DMX_TORCH_OPS=0 switches those calls to the ctypes binding; so does an op library that cannot be loaded
+(missing, or built against another torch): one warning, then ctypes -- the same HIP kernels either way.  Neither binding has a
+CPU fallback: without libdiffmusic_hip.so everything raises."""
 import os
+import warnings
 
 import torch
 
@@ -18,8 +22,9 @@ USE_TORCH_OPS = os.environ.get("DMX_TORCH_OPS", "1") not in ("", "0")
 _loaded = False
 
 OP_NAMES = ("sched_pred_x0", "cfg_combine", "sched_update", "randn_philox", "mask_mul", "l2norm", "resample_fwd", "resample_bwd",
-            "logmel_fwd", "logmel_bwd", "stft_mag_fwd", "stft_mag_bwd", "melscale_fwd", "unet_fwd", "vae_dec_fwd", "vae_dec_bwd",
-            "hifigan_fwd", "hifigan_bwd")
+            "logmel_fwd", "logmel_bwd", "stft_mag_fwd", "stft_mag_bwd", "melscale_fwd", "unet_fwd", "unet_fwd_ctx", "vae_dec_fwd",
+            "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "grad_normalize_")
+_usable = None
 
 
 def load():
@@ -33,6 +38,23 @@ def load():
         torch.ops.load_library(LIB_PATH)
         _loaded = True
     return torch.ops.diffmusic_hip
+
+
+def enabled():
+    """True when the facade should call torch.ops.diffmusic_hip.* (default), False for the ctypes binding: DMX_TORCH_OPS=0, or the
+    op library failed to load (warned about once; the HIP library itself is still required)."""
+    global _usable
+    if not USE_TORCH_OPS:
+        return False
+    if _usable is None:
+        try:
+            load()
+            _usable = True
+        except (RuntimeError, OSError) as e:
+            warnings.warn(f"torch.ops.diffmusic_hip is unavailable ({e}); using the ctypes binding of the same HIP entry points. "
+                          "Rebuild with `python -m diffmusic_amd.build`.", RuntimeWarning, stacklevel=2)
+            _usable = False
+    return _usable
 
 
 class _Hip:

@@ -140,7 +140,7 @@ class MusicLDMPipeline:
                 return self.unet.forward(x, torch.full((B,), float(t_host), device=dev), **half)   # uncond + s*(text-uncond) == text
             x2 = torch.cat([x, x], dim=0)
             eps2 = self.unet.forward(x2, torch.full((2 * B,), float(t_host), device=dev), **cond)
-            if ops.USE_TORCH_OPS:
+            if ops.enabled():
                 return ops.hip.cfg_combine(eps2, float(guidance_scale))          # torch.ops.diffmusic_hip.cfg_combine
             out = torch.empty_like(x)
             L.check(L.lib().dmx_sched_cfg_combine(C.c_void_p(eps2.data_ptr()), C.c_void_p(out.data_ptr()), out.numel(),

@@ -131,9 +131,12 @@ class GuidedDDIMScheduler:
                 total = torch.linalg.vector_norm(loss)
                 dwav.mul_((loss / total.clamp_min(1e-30))[:, None])
                 loss = total.reshape(1)
-            inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
-            L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
-                    "grad_normalize")
+            if ops.enabled():
+                inv_scale = ops.hip.grad_normalize_(dwav, float(self.grad_target))       # in place on dwav
+            else:
+                inv_scale = torch.empty(x0.shape[0], dtype=torch.float32, device=x0.device)
+                L.check(L.lib().dmx_grad_normalize(_p(dwav), _p(inv_scale), dwav.shape[0], dwav.shape[1], self.grad_target, _stream()),
+                        "grad_normalize")
         with stage("hifigan_bwd"):
             dmel = vocoder.backward(dwav)
         with stage("vae_bwd"):
@@ -157,7 +160,7 @@ class GuidedDDIMScheduler:
         e = model_output.detach().to(torch.float32).contiguous()
         B, n = x.shape[0], x[0].numel()
         lib = L.lib()
-        if ops.USE_TORCH_OPS:
+        if ops.enabled():
             x0 = ops.hip.sched_pred_x0(x, e, a_t)                  # torch.ops.diffmusic_hip.* (csrc_torch/torch_ops.cpp)
         else:
             x0 = torch.empty_like(x)
@@ -185,7 +188,7 @@ class GuidedDDIMScheduler:
                     sn = randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
                 noise = sn.to(torch.float32).contiguous()
         grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
-        if ops.USE_TORCH_OPS and grad_out is None:
+        if ops.enabled() and grad_out is None:
             with stage("sched_update"):
                 prev, x0_u = ops.hip.sched_update(mode, x, e, x0, g0, inv_scale, noise, a_t, a_p, sigma, float(rate), float(eps),
                                                   not self.per_clip_norm)

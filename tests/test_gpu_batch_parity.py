@@ -1,0 +1,223 @@
+"""-m gpu: parity at the BENCHMARK batch shapes.  The oracle-checked full-size tests (test_gpu_fullsize_parity.py) run one
+clip; the bench runs 8 (configs[1], configs[4]) or 4 (configs[2], configs[3]) clips per GPU, where the tile table, the split-K
+plans, the grouped pair launches and the GroupNorm launch plans are keyed on other (M, N, K, Z) and therefore take other code
+paths than at B = 1.  Here every stage of one full-size guided step is run at the bench batch and then clip by clip through the
+oracle-checked B = 1 path, on the same inputs per stage (HIP vs HIP, teacher-forced per stage): U-Net + CFG eps, VAE mel,
+vocoder waveform, operator loss + gradient, vocoder input-gradient, VAE input-gradient, and the whole `scheduler.step`
+(reference: diffmusic/schedulers/scheduling_dps.py:137-219 and siblings, pipeline_musicldm.py:690-766).
+
+Also here: a full-size N = 10 deterministic trajectory (DPS, MPGD) against the CPU oracle loop with the waveform SNR bar of
+SURVEY.md section 8d (>= 30 dB), and BASELINE.json configs[0] in full (MusicLDM + DDIM generation, 10 s, 50 steps, batch 1)
+against the oracle loop."""
+import json
+import math
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.join(os.path.dirname(__file__), "..")
+sys.path.insert(0, ROOT)
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def _cos(a, b):
+    a, b = a.detach().double().cpu().reshape(-1), b.detach().double().cpu().reshape(-1)
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def _dump(name, rep):
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", name), "w") as fh:
+            json.dump(rep, fh, indent=1)
+    except OSError:
+        pass
+
+
+def _stages(pipe, op, lat, cond, meas, L, t, sname, eta, rate, noise, gens, forced=None):
+    """One guided step stage by stage.  `forced` (dict of tensors) replaces the input of a stage by the given tensor so that the
+    batched and the per-clip runs of a stage see the same input; returns every stage output (clones)."""
+    import ctypes as C
+    from diffmusic_amd import _lib as Lb
+    f = forced or {}
+    sched = pipe.scheduler
+    out = {}
+    out["eps"] = pipe._unet_eps(lat, t, cond, pipe._bench["gscale"], True).clone()
+    eps = f.get("eps", out["eps"])
+    a_t = float(sched._ac[t])
+    x0 = ((lat - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5).contiguous()
+    zs = 1.0 / pipe.vae.config.scaling_factor
+    out["mel"] = pipe.vae.decode_hip(x0, z_scale=zs, keep_state=True).clone()
+    mel = f.get("mel", out["mel"])
+    out["wav"] = pipe.vocoder.forward(mel.contiguous()).clone()
+    wav = f.get("wav", out["wav"])
+    loss, dwav = op.guidance(wav.contiguous(), L, meas, "mel_spectrogram")
+    out["loss"], out["dwav"] = loss.clone().reshape(-1), dwav.clone()
+    dwav = f.get("dwav", out["dwav"]).clone()
+    inv = torch.empty(dwav.shape[0], dtype=torch.float32, device=dwav.device)
+    Lb.check(Lb.lib().dmx_grad_normalize(C.c_void_p(dwav.data_ptr()), C.c_void_p(inv.data_ptr()), dwav.shape[0], dwav.shape[1], 64.0,
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "grad_normalize")
+    out["dmel"] = (pipe.vocoder.backward(dwav).float() * inv[:, None, None]).clone()
+    dmel = f.get("dmel_scaled")
+    if dmel is None:
+        s = 64.0 / out["dmel"].abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-30)
+        out["dmel_scaled"], out["dmel_s"] = (out["dmel"] * s).to(Lb.act_dtype()).contiguous(), s.reshape(-1)
+        dmel, s = out["dmel_scaled"], out["dmel_s"]
+    else:
+        s = f["dmel_s"]
+    out["dx0"] = (pipe.vae.backward(dmel.contiguous(), z_scale=zs) / s[:, None, None, None]).clone()
+    kw = dict(eta=eta, ip_guidance_rate=rate, original_waveform_length=L, supervised_space="mel_spectrogram", measurement=meas,
+              vae=pipe.vae, vocoder=pipe.vocoder)
+    if sname in ("dsg", "diffmusic"):
+        kw["sample_noise"] = noise
+    else:
+        kw["generator"] = gens
+    so = sched.step(eps, t, lat, **kw)
+    out["prev_sample"], out["step_loss"] = so.prev_sample.clone(), so.loss.clone().reshape(-1)
+    return out
+
+
+BENCH_BATCH = {"dps_inpainting": 8, "dsg_phase_audioldm2": 4, "mpgd_sr4": 4, "diffmusic_style_audioldm2": 8}
+STEP_INDEX = {"dps_inpainting": 60, "dsg_phase_audioldm2": 100, "mpgd_sr4": 140, "diffmusic_style_audioldm2": 250}
+# forward outputs and the update: 2e-3 (the tolerance of test_fullsize_guided_step_is_per_clip); input-gradients: the batched and
+# the per-clip sweep differentiate tapes whose 16-bit activations differ in the last bit (other tiles, other summation order), so a
+# few leaky-relu' masks sit on the other side of 0: direction cosine >= 0.999 and rel-L2 <= 3e-2
+FWD_TOL, GRAD_TOL, GRAD_COS = 2e-3, 3e-2, 0.999
+
+
+@pytest.mark.parametrize("wl", sorted(BENCH_BATCH))
+def test_bench_batch_step_matches_per_clip(wl):
+    import bench
+    dev = torch.device("cuda")
+    B = BENCH_BATCH[wl]
+    assert B == bench.WORKLOADS[wl][5]
+    pname, sname, eta, rate, task, _, _ = bench.WORKLOADS[wl]
+    pipe, op, meas, lat, cond, L = bench.build_problem(B, 0, dev, wl)
+    t = pipe.scheduler._timesteps_host[STEP_INDEX[wl]]
+    noise = torch.randn(lat.shape, generator=torch.Generator().manual_seed(123)).to(dev)
+    gens = pipe._bench["gens"]
+    big = _stages(pipe, op, lat, cond, meas, L, t, sname, eta, rate, noise, gens)
+    torch.cuda.synchronize()
+    rep = {"workload": wl, "batch": B, "timestep": t}
+    keys_fwd = ("eps", "mel", "wav", "loss", "dwav", "prev_sample", "step_loss")
+    keys_grad = ("dmel", "dx0")
+    worst = {k: 0.0 for k in keys_fwd + keys_grad}
+    worst_cos = {k: 1.0 for k in keys_grad}
+    for i in range(B):
+        ci = {k: (torch.cat([v[i:i + 1], v[B + i:B + i + 1]]).contiguous() if v is not None else None) for k, v in cond.items()}
+        forced = {k: big[k][i:i + 1].contiguous() for k in ("eps", "mel", "wav", "dwav", "dmel_scaled")}
+        forced["dmel_s"] = big["dmel_s"][i:i + 1]
+        one = _stages(pipe, op, lat[i:i + 1].contiguous(), ci, meas[i:i + 1].contiguous(), L, t, sname, eta, rate,
+                      noise[i:i + 1].contiguous(), gens[i:i + 1], forced)
+        for k in keys_fwd + keys_grad:
+            worst[k] = max(worst[k], _rel(big[k][i:i + 1], one[k]))
+        for k in keys_grad:
+            worst_cos[k] = min(worst_cos[k], _cos(big[k][i:i + 1], one[k]))
+    rep.update({f"rel_{k}": v for k, v in worst.items()})
+    rep.update({f"cos_{k}": v for k, v in worst_cos.items()})
+    print("\n" + "\n".join(f"  {k:>20s}: {v:.3e}" if isinstance(v, float) else f"  {k:>20s}: {v}" for k, v in rep.items()))
+    _dump(f"batch_parity_{wl}.json", rep)
+    assert all(math.isfinite(v) for v in rep.values() if isinstance(v, float)), rep
+    for k in keys_fwd:
+        assert worst[k] < FWD_TOL, (k, rep)
+    for k in keys_grad:
+        assert worst[k] < GRAD_TOL and worst_cos[k] > GRAD_COS, (k, rep)
+
+
+def _snr_db(ref, got):
+    ref, got = ref.double().reshape(-1), got.double().reshape(-1)
+    return float(10 * torch.log10(ref.pow(2).sum() / (ref - got).pow(2).sum().clamp_min(1e-300)))
+
+
+@pytest.mark.parametrize("wl", ["dps_inpainting", "mpgd_sr4"])
+def test_fullsize_short_trajectory_snr(wl):
+    """deterministic samplers (eta = 0), N = 10 run at production size, one clip: the product pipeline
+    (`Pipeline.__call__`, all HIP) against the oracle loop (pipeline_musicldm.py:690-799 restated on fp32 CPU torch)."""
+    import bench
+    from oracle import schedulers as OS
+    from tests.test_gpu_fullsize_parity import _oracle_nets, _oracle_op
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    dev = torch.device("cuda")
+    pname, sname, eta, rate, task, _, _ = bench.WORKLOADS[wl]
+    N = 10
+    pipe, op, meas, lat, cond, L = bench.build_problem(1, 0, dev, wl)
+    pe = cond["class_labels"][:1]
+    out = pipe(prompt_embeds=pe, negative_prompt_embeds=pe, audio_length_in_s=bench.SECONDS, num_inference_steps=N,
+               guidance_scale=bench.GUIDANCE_SCALE, latents=lat.clone(), measurement=meas, ip_guidance_rate=rate, eta=eta,
+               show_progress=False, output_type="np")
+    assert out.audios.shape == (1, L) and pipe.nan_restarts == 0
+    ru, rv, rh = _oracle_nets(pipe, wl)
+    rop = _oracle_op(task, op)
+    rs = OS.get_scheduler(sname)(operator=rop, **bench.SCHED_CFG)
+    rs.set_timesteps(N)
+    x, pec = lat.cpu().float(), pe.cpu()
+    yr = rop.forward(bench.synth_clip(0, L)[None])
+    losses = []
+    for t in [int(v) for v in rs.timesteps]:
+        with torch.no_grad():
+            e2 = ru(torch.cat([x, x]), t, class_labels=torch.cat([pec, pec]))[0]
+        e = e2[:1] + bench.GUIDANCE_SCALE * (e2[1:] - e2[:1])
+        so = rs.step(e, t, x, eta=eta, measurement=yr, vae=rv, vocoder=rh, original_waveform_length=L, ip_guidance_rate=rate,
+                     supervised_space="mel_spectrogram")
+        x = so.prev_sample.detach()
+        losses.append(float(so.loss.reshape(-1)[0]))
+    with torch.no_grad():
+        wav = rh(rv.decode(x / rv.config.scaling_factor).sample.squeeze(1))[:, :L]
+    snr = _snr_db(wav, torch.from_numpy(out.audios))
+    hip_losses = [float(l.reshape(-1)[0]) for l in pipe.last_losses]
+    lrel = max(abs(a - b) / abs(b) for a, b in zip(hip_losses, losses))
+    print(f"\n  {wl}: N={N} full-size waveform SNR vs oracle loop {snr:.1f} dB; worst per-step loss rel err {lrel:.2e}")
+    _dump(f"trajectory_{wl}.json", {"workload": wl, "steps": N, "snr_db": snr, "loss_rel_worst": lrel, "oracle_losses": losses,
+                                    "hip_losses": hip_losses})
+    assert snr >= 30.0
+    assert lrel < 1e-2
+
+
+def test_config1_ddim_generation_full_run():
+    """BASELINE.json configs[0] in full: MusicLDM + DDIM music generation, 10 s, 50 steps, batch 1, guidance 2.0 -- the product
+    pipeline on the GPU against the oracle loop on the CPU (the reference's loop: pipeline_musicldm.py:690-766 with the DDIM
+    formula of scheduling_ddim.py:58-104, final decode :772-781)."""
+    import bench
+    from diffmusic_amd.pipelines import get_pipeline
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd import inverse_problem as P
+    from diffmusic_amd.torch_utils import randn_tensor
+    from oracle import schedulers as OS, operators as OO
+    from tests.test_gpu_fullsize_parity import _oracle_nets
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    dev = torch.device("cuda")
+    N, L = 50, bench.SECONDS * bench.SR
+    pipe = get_pipeline("musicldm").from_pretrained("synthetic", seed=0).to(dev)
+    pipe.scheduler = get_scheduler("ddim")(operator=P.IdentityOperator(bench.SR), **bench.SCHED_CFG)
+    pe = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(7)), dim=-1)
+    ne = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(8)), dim=-1)   # cond != uncond
+    lat = randn_tensor((1, 8, 250, 16), generator=[torch.Generator().manual_seed(0)], device=dev, dtype=torch.float32)
+    kw = dict(prompt_embeds=pe, negative_prompt_embeds=ne, audio_length_in_s=bench.SECONDS, num_inference_steps=N,
+              guidance_scale=bench.GUIDANCE_SCALE, eta=0.0, show_progress=False)
+    out = pipe(latents=lat.clone(), output_type="np", **kw)
+    assert out.audios.shape == (1, L) and pipe.nan_restarts == 0
+    assert [int(t) for t in pipe.scheduler._timesteps_host][:2] == [981, 961] and pipe.scheduler._timesteps_host[-1] == 1
+    lat_hip = pipe(latents=lat.clone(), output_type="latent", **kw).audios
+    ru, rv, rh = _oracle_nets(pipe, "musicldm")
+    rs = OS.get_scheduler("ddim")(operator=OO.IdentityOperator(bench.SR), **bench.SCHED_CFG)
+    rs.set_timesteps(N)
+    x = lat.cpu().float()
+    with torch.no_grad():
+        for t in [int(v) for v in rs.timesteps]:
+            e2 = ru(torch.cat([x, x]), t, class_labels=torch.cat([ne, pe]))[0]
+            e = e2[:1] + bench.GUIDANCE_SCALE * (e2[1:] - e2[:1])
+            x = rs.step(e, t, x, eta=0.0).prev_sample
+        wav = rh(rv.decode(x / rv.config.scaling_factor).sample.squeeze(1))[:, :L]
+    r_lat = _rel(lat_hip, x)
+    snr = _snr_db(wav, torch.from_numpy(out.audios))
+    print(f"\n  config 1 (DDIM, 50 steps, 10 s): final latent rel-L2 {r_lat:.2e}, waveform SNR vs oracle loop {snr:.1f} dB")
+    _dump("config1_ddim_full.json", {"steps": N, "latent_rel": r_lat, "snr_db": snr})
+    assert r_lat < 1e-2
+    assert snr >= 30.0

@@ -56,12 +56,16 @@ def _oracle_op(task, op=None):
     return OO.SuperResolutionOperator(16000, 4, noiser=n)
 
 
-# workload -> tolerances on (eps, mel, wav, loss, cos(grad), prev)
+# workload -> index of the mid-trajectory timestep; every workload is also checked at the FIRST step of its schedule (t = 996 /
+# 999: alpha_bar = 1.5e-4, x0_hat = (x - sqrt(1 - a) eps) / sqrt(a) amplifies by 81x -- the fp16 range / NaN-retry trigger of
+# pipeline_musicldm.py:741-756) and at the LAST one (t = 1: alpha_bar_prev = final_alpha_cumprod)
 CASES = {"dps_inpainting": 60, "dsg_phase_audioldm2": 100, "mpgd_sr4": 140, "diffmusic_style_audioldm2": 250}
+WHICH = {"first": lambda wl: 0, "mid": lambda wl: CASES[wl], "last": lambda wl: -1}
 
 
+@pytest.mark.parametrize("which", ["mid", "first", "last"])
 @pytest.mark.parametrize("wl", sorted(CASES))
-def test_fullsize_teacher_forced_step(wl):
+def test_fullsize_teacher_forced_step(wl, which):
     import bench
     from diffmusic_amd import _lib as Lb
     from oracle import schedulers as OS
@@ -71,12 +75,12 @@ def test_fullsize_teacher_forced_step(wl):
     pipe, op, meas, lat, cond, L = bench.build_problem(1, 0, dev, wl)
     gscale = pipe._bench["gscale"]
     sched = pipe.scheduler
-    t = sched._timesteps_host[CASES[wl]]
+    t = sched._timesteps_host[WHICH[which](wl)]
     ru, rv, rh = _oracle_nets(pipe, wl)
     rop = _oracle_op(task, op)
     rs = OS.get_scheduler(sname)(operator=rop, **bench.SCHED_CFG)
     rs.set_timesteps(bench.WORKLOAD_STEPS.get(wl, bench.N_STEPS))
-    rep = {"workload": wl, "timestep": t}
+    rep = {"workload": wl, "which": which, "timestep": t}
 
     # ---- measurement operator on the same clip
     clip = bench.synth_clip(0, L)[None]
@@ -146,7 +150,7 @@ def test_fullsize_teacher_forced_step(wl):
     print("\n" + "\n".join(f"  {k:>20s}: {v:.3e}" if isinstance(v, float) else f"  {k:>20s}: {v}" for k, v in rep.items()))
     try:
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-        with open(os.path.join(ROOT, "gpurun_out", f"fullsize_parity_{wl}.json"), "w") as fh:
+        with open(os.path.join(ROOT, "gpurun_out", f"fullsize_parity_{wl}" + ("" if which == "mid" else "_" + which) + ".json"), "w") as fh:
             json.dump(rep, fh, indent=1)
     except OSError:
         pass
@@ -158,4 +162,8 @@ def test_fullsize_teacher_forced_step(wl):
     assert rep["operator_loss"] < 2e-3 and rep["operator_bwd"] < 2e-2, rep
     assert rep["step_loss"] < 1e-2, rep
     assert rep["step_prev_sample"] < 1e-2, rep
-    assert rep["vae_bwd_cos"] > 0.99 and rep["vocoder_bwd_cos"] > 0.97 and rep["step_grad_cos"] > 0.97, rep
+    # input-gradients: measured 1.0-1.6e-3 (VAE), 5.0-5.7e-2 / cos 0.9984-0.9987 (vocoder: leaky-relu' mask flips of the 16-bit
+    # activations), 4-8e-2 / cos 0.9968-0.9992 (whole step); asserted at measured + margin
+    assert rep["vae_bwd"] < 5e-3 and rep["vae_bwd_cos"] > 0.9999, rep
+    assert rep["vocoder_bwd"] < 8e-2 and rep["vocoder_bwd_cos"] > 0.995, rep
+    assert rep["step_grad"] < 0.12 and rep["step_grad_cos"] > 0.99, rep

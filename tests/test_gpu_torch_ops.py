@@ -75,31 +75,67 @@ def test_measurement_ops_equal_facade():
     assert torch.equal(inp._a_fwd(wav, L_), h.mask_mul(wav, inp._mask_on(wav.device), L_, L_))
 
 
-def test_network_ops_through_handles_equal_engines():
+def test_network_ops_through_handles_equal_engines(monkeypatch):
+    """The engines' default binding is torch.ops.diffmusic_hip.* (ops.enabled()); DMX_TORCH_OPS=0 is the ctypes binding of the same
+    launchers: bit-identical, for the three networks (MusicLDM and AudioLDM2 U-Nets) and the in-place gradient rescale."""
     from diffmusic_amd import _lib as L, ops
     from diffmusic_amd.engine import HifiGanEngine, VaeDecoderEngine, UNetEngine
     from tests.test_gpu_step import HIFI, VAE
     from tests.test_gpu_unet import SMALL
     h = ops.load()
+    assert ops.enabled()                                  # the product default goes through the custom ops
     g = torch.Generator().manual_seed(2)
     voc = HifiGanEngine(HIFI); voc.load_state_dict(voc.synth_state_dict(1))
-    mel = torch.randn(2, 40, 64, generator=g).to(L.act_dtype()).cuda()
-    wav = voc.forward(mel).clone()
-    ws = next(iter(voc._ws.values()))
-    assert torch.equal(h.hifigan_fwd(voc._h.value, mel, ws), wav)
-    d = torch.randn(wav.shape, generator=g).cuda()
-    assert torch.equal(h.hifigan_bwd(voc._h.value, d, 40, 64), voc.backward(d))
     vae = VaeDecoderEngine(VAE); vae.load_state_dict(vae.synth_state_dict(2))
-    z = torch.randn(2, 8, 10, 16, generator=g).cuda()
-    m = vae.decode_hip(z, 1.1, keep_state=True).clone()
-    wsv = next(iter(vae._ws.values()))
-    assert torch.equal(h.vae_dec_fwd(vae._h.value, z, 1.1, True, wsv), m)
-    dm = torch.randn(m.shape, generator=g).to(L.act_dtype()).cuda()
-    assert torch.equal(h.vae_dec_bwd(vae._h.value, dm, 1.1, 8), vae.backward(dm, 1.1))
     un = UNetEngine(SMALL); un.load_state_dict(un.synth_state_dict(9))
+    a2 = UNetEngine(dict(SMALL, class_embed_dim=0, attn_cross_dims=[0, 48, 64])); a2.load_state_dict(a2.synth_state_dict(3))
+    mel = torch.randn(2, 40, 64, generator=g).to(L.act_dtype()).cuda()
+    z = torch.randn(2, 8, 10, 16, generator=g).cuda()
     x = torch.randn(2, 8, 26, 16, generator=g).cuda()
     t = torch.full((2,), 501.0).cuda()
     cls = torch.randn(2, 512, generator=g).cuda()
-    eps = un.forward(x, t, cls).clone()
+    c0, c1 = torch.randn(2, 8, 48, generator=g).cuda(), torch.randn(2, 12, 64, generator=g).cuda()
+    m1 = torch.ones(2, 12).cuda(); m1[1, 9:] = 0
+
+    def run():
+        wav = voc.forward(mel).clone()
+        d = torch.randn(wav.shape, generator=torch.Generator().manual_seed(5)).cuda()
+        dmel = voc.backward(d).clone()
+        m16, m32 = vae.decode_hip(z, 1.1, keep_state=True, want_f32=True)
+        m16, m32 = m16.clone(), m32.clone()
+        dm = torch.randn(m16.shape, generator=torch.Generator().manual_seed(6)).to(L.act_dtype()).cuda()
+        dz = vae.backward(dm, 1.1).clone()
+        eps = un.forward(x, t, cls).clone()
+        eps2 = a2.forward(x, t, None, c0, c1, m1).clone()
+        return wav, dmel, m16, m32, dz, eps, eps2
+
+    via_ops = run()
+    monkeypatch.setattr(ops, "USE_TORCH_OPS", False)
+    assert not ops.enabled()
+    via_ctypes = run()
+    monkeypatch.setattr(ops, "USE_TORCH_OPS", True)
+    for a, b in zip(via_ops, via_ctypes):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    # direct calls through the handles
+    ws = next(iter(voc._ws.values()))
+    assert torch.equal(h.hifigan_fwd(voc._h.value, mel, ws), via_ctypes[0])
     wsu = next(iter(un._ws.values()))
-    assert torch.equal(h.unet_fwd(un._h.value, x, t, cls, wsu), eps)
+    assert torch.equal(h.unet_fwd(un._h.value, x, t, cls, wsu), via_ctypes[5])
+    # in-place gradient rescale
+    dw = (torch.randn(3, 4000, generator=g) * torch.tensor([1e-3, 1.0, 50.0])[:, None]).cuda()
+    dw2 = dw.clone()
+    inv = h.grad_normalize_(dw, 64.0)
+    inv2 = torch.empty(3, device="cuda")
+    L.check(L.lib().dmx_grad_normalize(_p(dw2), _p(inv2), 3, 4000, 64.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gn")
+    assert torch.equal(dw, dw2) and torch.equal(inv, inv2)
+    assert torch.allclose(dw.abs().amax(dim=1), torch.full((3,), 64.0, device="cuda"), rtol=1e-5)
+
+
+def test_ops_fall_back_to_ctypes_with_a_warning_when_the_op_library_is_missing(monkeypatch, tmp_path):
+    from diffmusic_amd import ops
+    monkeypatch.setattr(ops, "_loaded", False)
+    monkeypatch.setattr(ops, "_usable", None)
+    monkeypatch.setattr(ops, "LIB_PATH", str(tmp_path / "missing.so"))
+    with pytest.warns(RuntimeWarning, match="ctypes binding"):
+        assert not ops.enabled()
+    assert not ops.enabled()                              # warned once, stays on ctypes
