@@ -487,7 +487,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EM>
 int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int SMEM = NSTAGE * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
+  constexpr int SMEM = NSTAGE * (BM + BN) * 128;       // (the tap table of this kernel lives in a register, not in LDS)
+  static_assert(SMEM <= 160 * 1024, "tile ring exceeds the 160 KiB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, EM>),
@@ -571,6 +572,9 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
     case 16: return launch_glds<64, 128, 2, 2, 6>(d, stream);
     case 17: return launch_glds<128, 64, 2, 2, 6>(d, stream);
     case 18: return launch_glds<128, 128, 2, 2, 4>(d, stream);
+    // N = 128 layers at full resolution (VAE 128-channel 3x3 convolutions, M = 512 000): the 256 x 256 tile's wave layout (8 waves of
+    // 128 x 64) on a 512 x 128 block -- twice the MFMAs per barrier and per weight fetch of the 256 x 128 tile; its ring is all 160 KiB
+    case 19: return launch_glds<512, 128, 4, 2, 2>(d, stream);
     case 3: return launch_cfg<128, 128, 2, 2>(d, stream);
     case 4: return launch_cfg<128, 64, 2, 2>(d, stream);
     case 5: return launch_cfg<128, 32, 4, 1>(d, stream);
@@ -580,7 +584,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
 int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
   const bool gl = glds_ok(d);
   if (d.flags & EPI_SOFTBWD) return gl ? launch_by_cfg(1, d, stream) : DMX_ERR_SHAPE;   // (its one caller checks the span up front: vae.hip)
-  if (d.tile_cfg >= 1 && d.tile_cfg <= 18 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
+  if (d.tile_cfg >= 1 && d.tile_cfg <= 19 && ((d.tile_cfg > 2 && d.tile_cfg < 7) || gl)) return launch_by_cfg(d.tile_cfg, d, stream);
   {  // tuning hook: DMX_CFG_OVERRIDE="N:cfg,N:cfg" forces a tile configuration for large-M launches with that N
     static int ovN[8], ovC[8], nov = -1;
     if (nov < 0) {
@@ -615,6 +619,9 @@ int launch_dispatch(const GemmDesc& d, hipStream_t stream) {
     struct Cand { int cfg, bm, bn, slots; double eff; };
     static const Cand cands[] = {{1, 256, 256, 256, 0.95}, {7, 320, 256, 256, 0.93}, {8, 192, 256, 256, 0.88},
                                  {2, 256, 128, 256, 0.70}, {9, 320, 128, 256, 0.70}, {10, 192, 128, 256, 0.66},
+                                 // 512 x 128: same-device A/B on the VAE's M = 512 000, N = 128 convolutions: VAE forward + backward -0.25 ms
+                                 // against 256 x 128; slower on the U-Net's M = 64 000 (125 tiles for 256 CUs), which the rounds term excludes
+                                 {19, 512, 128, 256, 0.75},
                                  {3, 128, 128, 512, 0.66}};
     int best = 0;
     double bc = 1e30;
@@ -666,7 +673,7 @@ extern "C" int dmx_prof_end(double* total_ms, double* total_flops) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms += t;
     if (csv) fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%.4f,%.1f\n", r.M, r.N, r.K, r.Z, r.taps, r.flags, r.cfg, t, t > 0 ? r.flops / t / 1e9 : 0.0);
-    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10);   // gemm_glds_kernel, 8-wave tiles (256/320/192 rows)
+    const bool dma = r.cfg == 1 || r.cfg == 2 || (r.cfg >= 7 && r.cfg <= 10) || r.cfg == 19;   // gemm_glds_kernel, 8-wave tiles (192 ... 512 rows)
     if (dma) { g_dma_ms += t; g_dma_fl += r.flops; g_dma_by += r.bytes; ++g_dma_n; }
     fl += r.flops;
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
@@ -742,7 +749,7 @@ int splitk_plan(const GemmDesc& d, int* tile) {
   if ((d.N & 7) || (d.ldc & 3)) return 1;
   const int nk = (d.K + BK - 1) / BK;
   auto fits = [&](int ks) { return ks >= 2 && ks <= nk && (size_t)ks * d.M * d.N * sizeof(float) <= g_splitk_bytes; };
-  auto dma_tile = [](int t) { return t == 1 || t == 2 || (t >= 7 && t <= 18); };      // only the LDS-DMA kernel walks a K slice
+  auto dma_tile = [](int t) { return t == 1 || t == 2 || (t >= 7 && t <= 19); };      // only the LDS-DMA kernel walks a K slice
   if (d.tile_cfg >= 100) { *tile = d.tile_cfg % 100; return fits(d.tile_cfg / 100) && dma_tile(*tile) ? d.tile_cfg / 100 : 1; }
   if (d.tile_cfg) return 1;
   for (const TileEntry* e = g_tile_table; e->cfg; ++e)
