@@ -103,6 +103,12 @@ _SIGS = {
                                           C.c_int, C.c_float, C.c_float, C.c_void_p]),
     "dmx_audio_transform_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]),
+    "dmx_audio_is_fused": (C.c_int, [C.c_void_p, C.c_int]),
+    "dmx_audio_guidance_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
+    "dmx_audio_guidance_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p,
+                                         C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                         C.c_void_p]),
     "dmx_audio_stft_mag": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_stft_mag_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_melscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),

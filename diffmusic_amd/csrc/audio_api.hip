@@ -2,13 +2,66 @@
 #include "kernels.h"
 #include "../../include/diffmusic_hip.h"
 #include <vector>
+#include <cmath>
 void dmx_set_error(const char* fmt, ...);
 #define ST(s) ((hipStream_t)(s))
 
 struct dmx_audio {
   int n_fft, hop, bins, n_mels, hann, Npad, Kpad;
   float *table, *tableT, *fb;
+  // fused STFT -> mel path (stft_mel.hip): n_fft = 1024 only; tables built once from the same window / filterbank
+  bool fused = false;
+  void* fused_mem = nullptr;
+  DmxStftMelTables ft;
 };
+
+// twiddles, window and the two compacted views of the (bins x 64) filterbank for stft_mel.hip, in ONE device allocation
+static bool build_fused_tables(dmx_audio* a, const float* fb) {
+  const int N = a->n_fft, NBv = a->bins, NMv = a->n_mels, NBP = 576;
+  if (N != 1024 || NMv != 64) return false;
+  std::vector<int> klo(NMv, 0), klen(NMv, 0), mlo(NBP, 0), mlen(NBP, 0);
+  int kmax = 1, mmax = 1;
+  for (int m = 0; m < NMv; ++m) {
+    int lo = -1, hi = -1;
+    for (int k = 0; k < NBv; ++k) if (fb[(size_t)k * NMv + m] != 0.f) { if (lo < 0) lo = k; hi = k; }
+    if (lo >= 0) { klo[m] = lo; klen[m] = hi - lo + 1; if (klen[m] > kmax) kmax = klen[m]; }
+  }
+  for (int k = 0; k < NBv; ++k) {
+    int lo = -1, hi = -1;
+    for (int m = 0; m < NMv; ++m) if (fb[(size_t)k * NMv + m] != 0.f) { if (lo < 0) lo = m; hi = m; }
+    if (lo >= 0) { mlo[k] = lo; mlen[k] = hi - lo + 1; if (mlen[k] > mmax) mmax = mlen[k]; }
+  }
+  std::vector<float> fbc((size_t)kmax * NMv, 0.f), fbr((size_t)mmax * NBP, 0.f), win(N), tw(2 * (size_t)N);
+  for (int m = 0; m < NMv; ++m) for (int i = 0; i < klen[m]; ++i) fbc[(size_t)i * NMv + m] = fb[(size_t)(klo[m] + i) * NMv + m];
+  for (int k = 0; k < NBv; ++k) for (int i = 0; i < mlen[k]; ++i) fbr[(size_t)i * NBP + k] = fb[(size_t)k * NMv + mlo[k] + i];
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int n = 0; n < N; ++n) {
+    win[n] = a->hann ? (float)(0.5 - 0.5 * cos(two_pi * n / N)) : 1.f;       // periodic Hann (torch.hann_window default) / rectangular
+    tw[2 * n] = (float)cos(two_pi * n / N); tw[2 * n + 1] = (float)(-sin(two_pi * n / N));
+  }
+  size_t off = 0;
+  auto place = [&](size_t bytes) { const size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t o_tw = place(tw.size() * 4), o_win = place(win.size() * 4), o_klo = place(NMv * 4), o_klen = place(NMv * 4),
+               o_mlo = place(NBP * 4), o_mlen = place(NBP * 4), o_fbc = place(fbc.size() * 4), o_fbr = place(fbr.size() * 4);
+  char* d = nullptr;
+  if (hipMalloc(&d, off) != hipSuccess) return false;
+  hipMemcpy(d + o_tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_win, win.data(), win.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_klo, klo.data(), NMv * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_klen, klen.data(), NMv * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_mlo, mlo.data(), NBP * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_mlen, mlen.data(), NBP * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_fbc, fbc.data(), fbc.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(d + o_fbr, fbr.data(), fbr.size() * 4, hipMemcpyHostToDevice);
+  a->fused_mem = d;
+  a->ft.tw = (const float2*)(d + o_tw); a->ft.win = (const float*)(d + o_win);
+  a->ft.klo = (const int*)(d + o_klo); a->ft.klen = (const int*)(d + o_klen); a->ft.fbc = (const float*)(d + o_fbc); a->ft.kmax = kmax;
+  a->ft.mlo = (const int*)(d + o_mlo); a->ft.mlen = (const int*)(d + o_mlen); a->ft.fbr = (const float*)(d + o_fbr); a->ft.mmax = mmax;
+  return true;
+}
+// state layout of the fused path: [waveform kept for transform_bwd: B x L][per-workgroup partial sums of the loss: B x parts]
+static float* fused_stash(void* state) { return (float*)state; }
+static float* fused_partials(const dmx_audio* a, void* state, int B, int L) { return (float*)state + align_up((size_t)B * L, 64); }
 
 static int frames_of(const dmx_audio* a, int L) { return 1 + L / a->hop; }
 struct AudioState { float *X, *mel_lin, *Y, *dframe; };
@@ -34,32 +87,60 @@ dmx_audio* dmx_audio_create(int n_fft, int hop, int n_mels, int window_hann, con
       hipMalloc(&a->fb, (size_t)a->bins * n_mels * 4) != hipSuccess) { dmx_set_error("hipMalloc failed"); delete a; return nullptr; }
   hipMemcpy(a->fb, fb_host, (size_t)a->bins * n_mels * 4, hipMemcpyHostToDevice);
   dmx_stft_tables(a->table, a->tableT, n_fft, a->bins, a->Npad, a->Kpad, window_hann, nullptr);
+  a->fused = build_fused_tables(a, fb_host);
   hipDeviceSynchronize();
   return a;
 }
 void dmx_audio_destroy(dmx_audio* a) {
   if (!a) return;
   hipFree(a->table); hipFree(a->tableT); hipFree(a->fb);
+  if (a->fused_mem) hipFree(a->fused_mem);
   delete a;
 }
 int dmx_audio_num_frames(const dmx_audio* a, int L) { return frames_of(a, L); }
 int dmx_audio_num_bins(const dmx_audio* a) { return a->bins; }
 size_t dmx_audio_state_bytes(const dmx_audio* a, int batch, int L) {
   const size_t M = (size_t)batch * frames_of(a, L);
-  return 4 * (align_up(M * a->Npad, 64) + align_up(M * a->n_mels, 64) + align_up(M * a->Kpad, 64) + align_up(M * a->n_fft, 64));
+  const size_t dense = 4 * (align_up(M * a->Npad, 64) + align_up(M * a->n_mels, 64) + align_up(M * a->Kpad, 64) + align_up(M * a->n_fft, 64));
+  const size_t fused = 4 * (align_up((size_t)batch * L, 64) + align_up((size_t)batch * dmx_stft_mel_parts(L, a->hop), 64));
+  return dense > fused ? dense : fused;        // (|STFT| operator calls and n_fft != 1024 use the dense-DFT layout)
 }
+int dmx_audio_is_fused(const dmx_audio* a, int L) { return a->fused && L >= 2 * a->n_fft ? 1 : 0; }
 int dmx_audio_transform_fwd(dmx_audio* a, const float* wav, long long wav_stride, float* mel_out, void* state, int batch, int L,
                             int power2, int to_db, float lo, float hi, void* stream) {
   if (L < a->n_fft / 2 + 1) { dmx_set_error("clip shorter than n_fft/2+1 (reflect pad)"); return DMX_ERR_SHAPE; }
   const int T = frames_of(a, L);
+  if (dmx_audio_is_fused(a, L)) {
+    // fused path: the spectrum is never stored; transform_bwd re-derives it from a copy of the waveform kept in `state`
+    if (hipMemcpy2DAsync(fused_stash(state), (size_t)L * 4, wav, (size_t)wav_stride * 4, (size_t)L * 4, batch, hipMemcpyDeviceToDevice,
+                         ST(stream)) != hipSuccess) return DMX_ERR_LAUNCH;
+    return dmx_stft_mel_fwd(a->ft, wav, wav_stride, nullptr, nullptr, 0, mel_out, nullptr, batch, L, a->hop, power2, to_db, lo, hi, ST(stream));
+  }
   AudioState s = carve(a, state, batch, L);
   int rc = dmx_stft_fwd(wav, wav_stride, a->table, s.X, batch, L, T, a->n_fft, a->hop, a->Npad, ST(stream));
   if (rc) return rc;
   return dmx_mel_fwd(s.X, a->fb, s.mel_lin, mel_out, batch * T, a->Npad, a->bins, a->n_mels, power2, to_db, lo, hi, ST(stream));
 }
+int dmx_audio_guidance_fwd(dmx_audio* a, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                           float* mel_out, void* state, int batch, int L, int power2, int to_db, float lo, float hi, void* stream) {
+  if (!dmx_audio_is_fused(a, L)) { dmx_set_error("fused guidance needs n_fft = 1024, 64 mel columns and a clip of >= 2048 samples"); return DMX_ERR_SHAPE; }
+  if (!ref) { dmx_set_error("guidance_fwd needs the reference transform"); return DMX_ERR_SHAPE; }
+  return dmx_stft_mel_fwd(a->ft, wav, wav_stride, mask, ref, ref_stride, mel_out, fused_partials(a, state, batch, L), batch, L, a->hop,
+                          power2, to_db, lo, hi, ST(stream));
+}
+int dmx_audio_guidance_bwd(dmx_audio* a, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                           float gscale, float* loss, float* dwav, long long dwav_stride, int Lfull, void* state, int batch, int L,
+                           int power2, int to_db, float lo, float hi, void* stream) {
+  if (!dmx_audio_is_fused(a, L)) { dmx_set_error("fused guidance needs n_fft = 1024, 64 mel columns and a clip of >= 2048 samples"); return DMX_ERR_SHAPE; }
+  return dmx_stft_mel_bwd(a->ft, wav, wav_stride, mask, ref, ref_stride, nullptr, fused_partials(a, state, batch, L), gscale, loss, dwav,
+                          dwav_stride, Lfull, 0, batch, L, a->hop, power2, to_db, lo, hi, ST(stream));
+}
 int dmx_audio_transform_bwd(dmx_audio* a, const float* dmel, float* dwav, long long dwav_stride, void* state, int batch, int L,
                             int power2, int to_db, float lo, float hi, int accumulate, void* stream) {
   const int T = frames_of(a, L);
+  if (dmx_audio_is_fused(a, L))
+    return dmx_stft_mel_bwd(a->ft, fused_stash(state), L, nullptr, nullptr, 0, dmel, nullptr, 1.f, nullptr, dwav, dwav_stride, L, accumulate,
+                            batch, L, a->hop, power2, to_db, lo, hi, ST(stream));
   AudioState s = carve(a, state, batch, L);
   int rc = dmx_mel_bwd(s.X, a->fb, s.mel_lin, dmel, s.Y, batch * T, a->Npad, a->Kpad, a->bins, a->n_mels, power2, to_db, lo, hi, ST(stream));
   if (rc) return rc;

@@ -64,6 +64,20 @@ int dmx_mask_mul(const float* x, long long xs, const float* mask, float* y, long
 int dmx_melscale(const float* mag, const float* fb, float* mel, int B, int T, int bins, int n_mels, float lo, float hi, hipStream_t st);
 int dmx_absmax_normalize(float* x, float* inv_scale, int B, long long n, float target, hipStream_t st);
 
+// ---- stft_mel.hip (fused STFT -> mel -> dB [-> L2] and its backward; n_fft = 1024, 64 mel columns)
+struct DmxStftMelTables {
+  const float2* tw;     // exp(-2 pi i m / 1024)
+  const float* win;     // analysis window
+  const int *klo, *klen; const float* fbc; int kmax;     // per mel column: first bin, bin count, weights [i][64]
+  const int *mlo, *mlen; const float* fbr; int mmax;     // per bin: first mel column, column count, weights [i][576]
+};
+int dmx_stft_mel_parts(int L, int hop);                  // workgroups per clip of the forward launch (= partial sums per clip)
+int dmx_stft_mel_fwd(const DmxStftMelTables& t, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                     float* mel_out, float* partial, int B, int L, int hop, int power2, int to_db, float lo, float hi, hipStream_t st);
+int dmx_stft_mel_bwd(const DmxStftMelTables& t, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                     const float* dmel, const float* partial, float gscale, float* loss, float* dwav, long long dwav_stride, int Lfull,
+                     int accumulate, int B, int L, int hop, int power2, int to_db, float lo, float hi, hipStream_t st);
+
 // ---- sched.hip
 int dmx_pred_x0(const float* x, const float* eps, float* x0, long long n, float sqrt_a, float sqrt_1ma, hipStream_t st);
 int dmx_cfg_combine(const float* eps2, float* out, long long n, float scale, hipStream_t st);

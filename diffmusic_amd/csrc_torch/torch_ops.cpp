@@ -148,6 +148,27 @@ at::Tensor logmel_bwd(int64_t audio, const at::Tensor& dmel, const at::Tensor& s
                              (float)lo, (float)hi, 0, cur_stream()), "logmel_bwd");
   return dwav;
 }
+// fused guidance of the mel-space operators (include/diffmusic_hip.h dmx_audio_guidance_{fwd,bwd}): (loss (B), dwav (B, Lfull))
+std::tuple<at::Tensor, at::Tensor> mel_guidance(int64_t audio, const at::Tensor& wav, const std::optional<at::Tensor>& mask, const at::Tensor& ref,
+                                                at::Tensor state, int64_t L, int64_t Lfull, bool power2, bool to_db, double lo, double hi, double gscale) {
+  dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
+  TORCH_CHECK(wav.is_cuda() && wav.scalar_type() == at::kFloat && wav.dim() == 2 && wav.stride(1) == 1 && wav.size(1) >= L, "wav must be (B, >= L) fp32 on the GPU");
+  DMX_DEVICE_OF(wav);
+  f32_cuda(ref, "ref");
+  if (mask) { f32_cuda(*mask, "mask"); TORCH_CHECK(mask->numel() >= L && mask->device() == wav.device(), "mask must hold L samples"); }
+  const int B = (int)wav.size(0), T = dmx_audio_num_frames(a, (int)L);
+  TORCH_CHECK(ref.device() == wav.device() && (ref.numel() == (int64_t)T * 64 || ref.numel() == (int64_t)B * T * 64), "ref must be (B or 1, frames, 64)");
+  TORCH_CHECK(state.is_cuda() && (size_t)state.nbytes() >= dmx_audio_state_bytes(a, B, (int)L), "state buffer too small");
+  TORCH_CHECK(Lfull >= L, "Lfull < L");
+  const long long rs = ref.numel() == (int64_t)T * 64 && B > 1 ? 0 : (long long)T * 64;
+  at::Tensor loss = at::empty({B}, wav.options()), dwav = at::empty({B, Lfull}, wav.options());
+  ok(dmx_audio_guidance_fwd(a, wav.data_ptr<float>(), wav.stride(0), fp(mask), ref.data_ptr<float>(), rs, nullptr, state.data_ptr(), B, (int)L,
+                            power2, to_db, (float)lo, (float)hi, cur_stream()), "mel_guidance (forward)");
+  ok(dmx_audio_guidance_bwd(a, wav.data_ptr<float>(), wav.stride(0), fp(mask), ref.data_ptr<float>(), rs, (float)gscale, loss.data_ptr<float>(),
+                            dwav.data_ptr<float>(), Lfull, (int)Lfull, state.data_ptr(), B, (int)L, power2, to_db, (float)lo, (float)hi, cur_stream()),
+     "mel_guidance (backward)");
+  return {loss, dwav};
+}
 at::Tensor stft_mag_fwd(int64_t audio, const at::Tensor& wav, const at::Tensor& state, int64_t L) {
   dmx_audio* a = reinterpret_cast<dmx_audio*>(audio);
   TORCH_CHECK(wav.is_cuda() && wav.scalar_type() == at::kFloat && wav.dim() == 2 && wav.stride(1) == 1, "wav must be (B, >= L) fp32 on the GPU");
@@ -259,6 +280,8 @@ TORCH_LIBRARY(diffmusic_hip, m) {
   m.def("resample_bwd(Tensor dy, Tensor h, Tensor? h_rev, int Lin, int Lfull, int orig, int new_, int off) -> Tensor", &resample_bwd);
   m.def("logmel_fwd(int audio, Tensor wav, Tensor state, int L, bool power2, bool to_db, float lo, float hi) -> Tensor", &logmel_fwd);
   m.def("logmel_bwd(int audio, Tensor dmel, Tensor state, int L, bool power2, bool to_db, float lo, float hi) -> Tensor", &logmel_bwd);
+  m.def("mel_guidance(int audio, Tensor wav, Tensor? mask, Tensor ref, Tensor state, int L, int Lfull, bool power2, bool to_db, float lo, float hi, "
+        "float gscale) -> (Tensor, Tensor)", &mel_guidance);
   m.def("stft_mag_fwd(int audio, Tensor wav, Tensor state, int L) -> Tensor", &stft_mag_fwd);
   m.def("stft_mag_bwd(int audio, Tensor dmag, Tensor state, int L, int Lfull) -> Tensor", &stft_mag_bwd);
   m.def("melscale_fwd(int audio, Tensor mag, float lo, float hi) -> Tensor", &melscale_fwd);

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from .. import _lib as L
+from .. import ops
 from . import dsp
 
 _NEG, _POS = -3.0e38, 3.0e38
@@ -80,6 +81,32 @@ class SpectralFrontend:
         L.check(L.lib().dmx_audio_transform_bwd(self._h, _p(dmel), _p(dwav), dwav.stride(0), _p(self._state), B, length, int(power2),
                                                 int(to_db), lo, hi, 0, _stream()), "audio_transform_bwd")
         return dwav
+
+    def fused(self, length):
+        """True when the fused STFT -> mel kernels (csrc/stft_mel.hip: n_fft = 1024) cover this handle and clip length."""
+        return bool(L.lib().dmx_audio_is_fused(self._h, int(length)))
+
+    def guidance(self, wav, length, ref, mask=None, power2=True, to_db=True, lo=_NEG, hi=_POS, gscale=1.0):
+        """Fused guidance pair: loss[b] = ||ref[b] - transform(wav[b, :length] * mask)||_2 and dwav = gscale * dloss/dwav, (B, wav.shape[1])
+        with zeros past `length` -- one forward and one backward launch, no spectrum in HBM (torch.ops.diffmusic_hip.mel_guidance or
+        the ctypes binding of dmx_audio_guidance_{fwd,bwd})."""
+        assert wav.dtype == torch.float32 and wav.is_cuda and wav.stride(1) == 1 and ref.dtype == torch.float32 and ref.is_contiguous()
+        B, full = wav.shape
+        st = self._get_state(B, length, wav.device)
+        if ops.enabled():
+            return ops.hip.mel_guidance(self._h.value, wav, mask, ref, st, int(length), int(full), bool(power2), bool(to_db), float(lo),
+                                        float(hi), float(gscale))
+        T = self.frames(length)
+        assert ref.numel() in (T * self.n_mels, B * T * self.n_mels), (ref.shape, B, T)
+        rs = 0 if (ref.numel() == T * self.n_mels and B > 1) else T * self.n_mels
+        loss = torch.empty(B, dtype=torch.float32, device=wav.device)
+        dwav = torch.empty(B, full, dtype=torch.float32, device=wav.device)
+        lib = L.lib()
+        L.check(lib.dmx_audio_guidance_fwd(self._h, _p(wav), wav.stride(0), _p(mask), _p(ref), rs, None, _p(st), B, length, int(power2),
+                                           int(to_db), lo, hi, _stream()), "audio_guidance_fwd")
+        L.check(lib.dmx_audio_guidance_bwd(self._h, _p(wav), wav.stride(0), _p(mask), _p(ref), rs, gscale, _p(loss), _p(dwav), full, full,
+                                           _p(st), B, length, int(power2), int(to_db), lo, hi, _stream()), "audio_guidance_bwd")
+        return loss, dwav
 
     def stft_mag(self, wav, length):
         B = wav.shape[0]
@@ -179,8 +206,23 @@ class _MelOperator(BaseOperator):
     def _a_bwd(self, dy, wav_full_len):
         raise NotImplementedError
 
+    def _fused_mask_tensor(self, device, length):
+        return None
+
+    fused_mask = False        # True: A(.) is a per-sample mask (or the identity) that the fused mel kernels apply on load / on store
+
     def guidance(self, wav, length, measurement, supervised_space):
+        if supervised_space == "mel_spectrogram" and self.fused_mask and self.frontend.fused(length):
+            # mask, STFT, mel, dB, L2 and the whole backward in two launches; y = A(wav) is never materialised
+            lo, hi = self.clamp if self.clamp else (_NEG, _POS)
+            ref = self._ref(measurement, "mel_spectrogram", lambda m: self._mel(m.reshape(m.shape[0], -1)).clone())
+            return self.frontend.guidance(wav, length, ref, self._fused_mask_tensor(wav.device, length), True, True, lo, hi)
         y = self._a_fwd(wav, length)                                         # (B, L') contiguous fp32
+        if supervised_space == "mel_spectrogram" and self.frontend.fused(y.shape[1]):
+            lo, hi = self.clamp if self.clamp else (_NEG, _POS)
+            ref = self._ref(measurement, "mel_spectrogram", lambda m: self._mel(m.reshape(m.shape[0], -1)).clone())
+            loss, dy = self.frontend.guidance(y, y.shape[1], ref, None, True, True, lo, hi)
+            return loss, self._a_bwd(dy, wav.shape[1])
         if supervised_space == "wav_form":
             m32 = self._ref(measurement, "wav_form", lambda m: m.reshape(m.shape[0], -1).contiguous())
             loss, dy = l2_loss(m32, y)
@@ -195,6 +237,8 @@ class _MelOperator(BaseOperator):
 
 
 class IdentityOperator(_MelOperator):                     # operator.py:17-45
+    fused_mask = True
+
     def __init__(self, sample_rate):
         self._init_mel(sample_rate)
 
@@ -215,6 +259,12 @@ class IdentityOperator(_MelOperator):                     # operator.py:17-45
 
 class MusicInpaintingOperator(_MelOperator):              # operator.py:48-133
     clamp = None                                            # transform = wav2mel without clamp (operator.py:123-124)
+    fused_mask = True
+
+    def _fused_mask_tensor(self, device, length):
+        if length != self.mask.shape[1]:
+            raise ValueError(f"mask length {self.mask.shape[1]} != waveform length {length}")
+        return self._mask_on(device)
 
     def __init__(self, audio_length_in_s, sample_rate, mask_type, start_inpainting_s, end_inpainting_s, mask_percentage,
                  mask_duration_s, interval_s, noiser=None):
@@ -299,6 +349,8 @@ class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
         if supervised_space != "mel_spectrogram":
             raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
         ref = self._ref(measurement, "mel_spectrogram", lambda m: self.frontend.melscale(m, -80.0, 80.0))
+        if self.frontend.fused(length):
+            return self.frontend.guidance(wav, length, ref, None, False, False, -80.0, 80.0)
         pred = self.frontend.transform_fwd(wav, length, False, False, -80.0, 80.0)   # |STFT| -> MelScale -> clamp
         loss, dmel = l2_loss(ref, pred)
         dwav = torch.zeros(wav.shape[0], wav.shape[1], dtype=torch.float32, device=wav.device)

@@ -23,7 +23,7 @@ _loaded = False
 
 OP_NAMES = ("sched_pred_x0", "cfg_combine", "sched_update", "randn_philox", "mask_mul", "l2norm", "resample_fwd", "resample_bwd",
             "logmel_fwd", "logmel_bwd", "stft_mag_fwd", "stft_mag_bwd", "melscale_fwd", "unet_fwd", "unet_fwd_ctx", "vae_dec_fwd",
-            "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "grad_normalize_")
+            "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "grad_normalize_", "mel_guidance")
 _usable = None
 
 

@@ -133,12 +133,26 @@ int dmx_audio_num_frames(const dmx_audio* a, int L);
 int dmx_audio_num_bins(const dmx_audio* a); /* n_fft / 2 + 1 */
 size_t dmx_audio_state_bytes(const dmx_audio* a, int batch, int L);
 /* wav (B, L) fp32 (row stride wav_stride) -> mel_out (B, frames, n_mels) fp32.  power2: |X|^2 (1) or |X| (0);
- * to_db: 10*log10(max(.,1e-10)); then clamp(lo, hi).  `state` keeps the spectrum for the backward call. */
+ * to_db: 10*log10(max(.,1e-10)); then clamp(lo, hi).  `state` keeps what the backward call needs (the spectrum on the dense-DFT path,
+ * a copy of the waveform on the fused n_fft = 1024 path). */
 int dmx_audio_transform_fwd(dmx_audio* a, const float* wav, long long wav_stride, float* mel_out, void* state, int batch, int L,
                             int power2, int to_db, float lo, float hi, void* stream);
 /* dmel (B, frames, n_mels) -> dwav (B, L) (row stride dwav_stride), same flags as the forward call */
 int dmx_audio_transform_bwd(dmx_audio* a, const float* dmel, float* dwav, long long dwav_stride, void* state, int batch, int L,
                             int power2, int to_db, float lo, float hi, int accumulate, void* stream);
+/* Fused guidance pair for n_fft = 1024 (dmx_audio_is_fused): everything between the vocoder output and its gradient in one forward and
+ * one backward launch -- y = wav * mask (mask NULL: y = wav; MusicInpaintingOperator.forward, operator.py:132-133), transform(y) as
+ * above (operator.py:23-33 / :143-147), loss[b] = ||ref[b] - transform(y[b])||_2 (torch.linalg.norm, scheduling_dps.py:205-211) and
+ * dwav = gscale * d loss / d wav (torch.autograd.grad, scheduling_dps.py:212), written for samples [0, L) and zeroed on [L, Lfull).
+ * ref: (B or 1, frames, n_mels) with row stride ref_stride elements per clip (0 = one reference for all clips).  The spectrum is never
+ * stored: the backward launch recomputes it from wav.  `state` carries the per-workgroup partial sums of the loss from _fwd to _bwd
+ * (same stream).  mel_out may be NULL.  Returns DMX_ERR_SHAPE for handles / lengths the fused kernels do not cover. */
+int dmx_audio_is_fused(const dmx_audio* a, int L);
+int dmx_audio_guidance_fwd(dmx_audio* a, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                           float* mel_out, void* state, int batch, int L, int power2, int to_db, float lo, float hi, void* stream);
+int dmx_audio_guidance_bwd(dmx_audio* a, const float* wav, long long wav_stride, const float* mask, const float* ref, long long ref_stride,
+                           float gscale, float* loss, float* dwav, long long dwav_stride, int Lfull, void* state, int batch, int L,
+                           int power2, int to_db, float lo, float hi, void* stream);
 /* PhaseRetrievalOperator.forward: |torch.stft(wav)| as (B, n_fft/2+1, frames) fp32 */
 int dmx_audio_stft_mag(dmx_audio* a, const float* wav, long long wav_stride, float* mag, void* state, int batch, int L, void* stream);
 /* gradient of a loss on that magnitude (PhaseRetrievalOperator.forward, operator.py:156-163, differentiated by
