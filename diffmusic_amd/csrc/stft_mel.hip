@@ -6,8 +6,8 @@
 // diffmusic/schedulers/scheduling_dps.py:202-212.
 //
 // One wave owns one frame at a time: 1024 windowed samples (reflect padding and the optional measurement mask applied on load,
-// 256-byte coalesced reads; neighbouring frames overlap by 86 % and are served by L2) go through a radix-4 Stockham FFT in LDS
-// (five passes, the first one straight from registers), |X|^2 stays in LDS, the mel filterbank is applied from a compacted table
+// 256-byte coalesced reads, the next frame's samples fetched under this frame's arithmetic; neighbouring frames overlap by 86 % and
+// are served by L2) go through an in-place radix-4 Stockham FFT in LDS (five passes), |X|^2 stays in LDS, the mel filterbank is applied from a compacted table
 // (the <= 2 % non-zero weights of the triangular bank, one mel column per lane, 256-byte reads) and the dB / clamp tail runs in
 // registers.  Forward writes the (B, T, 64) mel tensor and per-workgroup partial sums of (ref - mel)^2; nothing else touches HBM
 // (no framed signal, no complex spectrum, no power spectrogram: the dense-DFT path moved ~50x the algorithmic bytes).
@@ -114,18 +114,23 @@ __device__ __forceinline__ void fft1024(float2* buf, const float2* s_tw, int lan
   fft_pass<256, INV>(buf, s_tw, lane);
 }
 
-// windowed, masked, reflect-padded frame f of clip b -> buf (imaginary parts zero)
-__device__ __forceinline__ void load_frame(const SmParams& P, int b, int f, float2* buf, const float* s_win, int lane) {
+// masked, reflect-padded samples n = lane + 64 j of frame f of clip b -> registers (frames past the end: zeros, nothing is read)
+__device__ __forceinline__ void fetch_frame(const SmParams& P, int b, int f, float (&x)[16], int lane) {
   const float* w = P.wav + (long long)b * P.wav_stride;
   const int p0 = f * P.hop - PADH;
+  const bool live = f < P.T;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int n = lane + 64 * j;
-    const int s = fold_reflect(p0 + n, P.L);
-    float v = w[s];
-    if (P.mask) v *= P.mask[s];
-    buf[n] = make_float2(v * s_win[n], 0.f);
+    const int s = fold_reflect(p0 + lane + 64 * j, P.L);
+    float v = 0.f;
+    if (live) { v = w[s]; if (P.mask) v *= P.mask[s]; }
+    x[j] = v;
   }
+}
+// registers -> LDS with the analysis window (kept in registers: lane l only ever needs win[l + 64 j]); imaginary parts zero
+__device__ __forceinline__ void put_frame(const float (&x)[16], const float (&win)[16], float2* buf, int lane) {
+#pragma unroll
+  for (int j = 0; j < 16; ++j) buf[lane + 64 * j] = make_float2(x[j] * win[j], 0.f);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -160,22 +165,26 @@ constexpr int FWD_FPW = 4;           // frames per wave of the forward kernel (1
 
 __global__ __launch_bounds__(256) void stft_mel_fwd_kernel(const SmParams P) {
   __shared__ float2 s_tw[NF];
-  __shared__ float s_win[NF];
   __shared__ float2 s_buf[4][NF];
   __shared__ float s_pw[4][NBP];
   __shared__ float s_red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
-  for (int i = tid; i < NF; i += 256) { s_tw[i] = P.tw[i]; s_win[i] = P.win[i]; }
+  for (int i = tid; i < NF; i += 256) s_tw[i] = P.tw[i];
+  float win[16], xs[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) win[j] = P.win[lane + 64 * j];
   __syncthreads();
   float2* buf = s_buf[wave];
   float* pw = s_pw[wave];
   float sq = 0.f;
   const int f0 = blockIdx.x * (4 * FWD_FPW);
+  fetch_frame(P, b, f0 + wave, xs, lane);
   for (int i = 0; i < FWD_FPW; ++i) {
     const int f = f0 + wave + 4 * i;                       // the four waves walk neighbouring frames together (shared cache lines)
     if (f >= P.T) break;                                   // wave-uniform
-    load_frame(P, b, f, buf, s_win, lane);
+    put_frame(xs, win, buf, lane);
+    if (i + 1 < FWD_FPW) fetch_frame(P, b, f + 4, xs, lane);      // in flight under this frame's FFT
     fft1024<false>(buf, s_tw, lane);
     const float v = power_and_mel(P, buf, pw, lane);
     const float o = mel_tail(P, v);
@@ -195,11 +204,12 @@ __global__ __launch_bounds__(256) void stft_mel_fwd_kernel(const SmParams P) {
   }
 }
 
-constexpr int BWD_MAX_CHUNK = 2560;  // output samples per workgroup (16 hops of 160)
+// output samples per workgroup (8 hops of 160): 15 frames touch a chunk, ~4 per wave; with 20 KB of accumulators two workgroups share a
+// CU (a 2560-sample chunk needs 27 % fewer FFTs per sample but leaves one workgroup per CU alone with its load latencies)
+constexpr int BWD_MAX_CHUNK = 1280;
 
 __global__ __launch_bounds__(256) void stft_mel_bwd_kernel(const SmParams P) {
   __shared__ float2 s_tw[NF];
-  __shared__ float s_win[NF];
   __shared__ float2 s_buf[4][NF];
   __shared__ float s_pw[4][NBP];
   __shared__ float s_dv[4][NM];
@@ -209,7 +219,10 @@ __global__ __launch_bounds__(256) void stft_mel_bwd_kernel(const SmParams P) {
   const int b = blockIdx.y;
   const int L = P.L, hop = P.hop;
   const int s0 = blockIdx.x * P.chunk, s1 = min(s0 + P.chunk, L);
-  for (int i = tid; i < NF; i += 256) { s_tw[i] = P.tw[i]; s_win[i] = P.win[i]; }
+  for (int i = tid; i < NF; i += 256) s_tw[i] = P.tw[i];
+  float win[16], xs[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) win[j] = P.win[lane + 64 * j];
   for (int i = tid; i < 4 * BWD_MAX_CHUNK; i += 256) (&s_acc[0][0])[i] = 0.f;
   if (tid == 0) {
     float inv = 0.f;
@@ -237,8 +250,10 @@ __global__ __launch_bounds__(256) void stft_mel_bwd_kernel(const SmParams P) {
   float* pw = s_pw[wave];
   float* dv = s_dv[wave];
   float* acc = s_acc[wave];
+  fetch_frame(P, b, flo + wave, xs, lane);
   for (int f = flo + wave; f <= fhi; f += 4) {
-    load_frame(P, b, f, buf, s_win, lane);
+    put_frame(xs, win, buf, lane);
+    if (f + 4 <= fhi) fetch_frame(P, b, f + 4, xs, lane);         // in flight under this frame's two FFTs
     fft1024<false>(buf, s_tw, lane);
     const float v = power_and_mel(P, buf, pw, lane);
     // d(loss)/d(mel_out) -> d/d(mel_lin): clamp passes the gradient inside (lo, hi) only, dB is 10 / ln 10 / v above the 1e-10 floor
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(256) void stft_mel_bwd_kernel(const SmParams P) {
         if (pass == 0) { s = sr; ok = sr >= 0 && sr < L; }
         else if (pass == 1) { s = -sr; ok = sr < 0; }
         else { s = 2 * (L - 1) - sr; ok = sr >= L; }
-        if (ok && s >= s0 && s < s1) acc[s - s0] += buf[n].x * s_win[n];
+        if (ok && s >= s0 && s < s1) acc[s - s0] += buf[n].x * win[j];
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       if (pass == 0 && p0 >= 0 && p0 + NF <= L) break;     // interior frame: no reflections (wave-uniform)
