@@ -126,6 +126,27 @@ def cpu_model_string():
     return "unknown"
 
 
+def cpu_share():
+    """CPUs this process may actually use: (host logical CPUs, affinity-set size, cgroup CPU quota or None).  On the GPU boxes of this
+    pool the affinity set is the whole host (256) while the container's cgroup grants 16 CPUs: threads beyond the quota only add
+    scheduling overhead (measured: the oracle did not finish a step in 7 minutes on 256 threads), so the quota is the share."""
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                          # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                                                 # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return os.cpu_count(), len(os.sched_getaffinity(0)), quota
+
+
 def cpu_baseline(seed_sd, threads, batch, n_meas):
     """The CPU restatement (oracle/, fp32 eager torch + autograd) timed on the host cores: `batch` clips, DPS steps.
     Returns seconds per (batch-`batch`) step over `n_meas` measured steps after 1 warm-up step."""
@@ -153,6 +174,7 @@ def cpu_baseline(seed_sd, threads, batch, n_meas):
         e = e2[:batch] + GUIDANCE_SCALE * (e2[batch:] - e2[:batch])
         x = sched.step(e, ts[i], x, eta=0.0, measurement=y, vae=vae, vocoder=voc, original_waveform_length=L,
                        ip_guidance_rate=ZETA, supervised_space="mel_spectrogram").prev_sample
+        print(f"[bench]   CPU oracle batch {batch}: step {i + 1}/{n_warm + n_meas} done", file=sys.stderr, flush=True)
     return (time.perf_counter() - t0) / n_meas
 
 
@@ -472,11 +494,14 @@ def main():
                               "collective": "all_gather of (clips_per_gpu, 160000) fp32 waveforms, once per call" if world > 1 else "none (single rank)"},
                "stage_ms": stages, "mel_path": mel_path, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting" and not strong:
-            affinity = len(os.sched_getaffinity(0))
-            threads = affinity if args.cpu_threads <= 0 else min(args.cpu_threads, affinity)   # the whole CPU share of this process
+            host_cpus, affinity, quota = cpu_share()
+            # the whole CPU share of this process: the cgroup quota where one is set; else the affinity set -- unless that is a whole
+            # many-core host (> 32), where this pool's documented per-GPU share of 16 is assumed (see cpu_share)
+            share = min(affinity, max(1, int(quota + 0.5))) if quota else (affinity if affinity <= 32 else 16)
+            threads = share if args.cpu_threads <= 0 else min(args.cpu_threads, affinity)
             sd = {"unet": pipe.unet.synth_state_dict(0), "vae": pipe.vae.synth_state_dict(1), "vocoder": pipe.vocoder.synth_state_dict(2)}
-            print(f"[bench] timing the CPU oracle on {threads} threads (host has {os.cpu_count()} logical CPUs, affinity {affinity}): "
-                  f"1 clip x (1 warm-up + 3 measured) steps ...", file=sys.stderr, flush=True)
+            print(f"[bench] timing the CPU oracle on {threads} threads (host has {host_cpus} logical CPUs, affinity {affinity}, cgroup CPU quota "
+                  f"{quota}): 1 clip x (1 warm-up + 3 measured) steps ...", file=sys.stderr, flush=True)
             sec1 = cpu_baseline(sd, threads, 1, 3)
             print(f"[bench] CPU oracle: {sec1:.2f} s per clip-step", file=sys.stderr, flush=True)
             cb = args.cpu_batch
@@ -495,7 +520,8 @@ def main():
                 print(f"[bench] CPU oracle: {secb:.2f} s per batch-{cb} step", file=sys.stderr, flush=True)
             v8 = 1.0 / (secb * (8.0 / cb)) if secb else 1.0 / (sec1 * 8)
             res["cpu_baseline"] = {"value": round(v8, 6), "unit": "steps/s (batch-8 step)" if cb == 8 else "steps/s (batch-8 equivalent, extrapolated)",
-                                   "cores": threads, "host_logical_cpus": os.cpu_count(), "affinity_cpus": affinity, "threads_used": threads,
+                                   "cores": threads, "host_logical_cpus": host_cpus, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+                                   "threads_used": threads, "threads_rule": "cgroup quota" if quota else ("affinity set" if affinity <= 32 else "16 (affinity set is the whole host, no cgroup quota visible)"),
                                    "kind": "port", "cpu_model": cpu_model_string(), "torch": torch.__version__,
                                    "batch1_seconds_per_step": round(sec1, 3), f"batch{cb}_seconds_per_step": round(secb, 3) if secb else None,
                                    "batch1_x8_steps_per_sec": round(1.0 / (sec1 * 8), 6),
