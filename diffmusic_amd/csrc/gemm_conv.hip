@@ -552,7 +552,12 @@ static const TileEntry g_tile_table[] = {
 
 bool glds_ok(const GemmDesc& d) {
   // operand spans must stay below 2 GiB for the 32-bit buffer offsets of the LDS-DMA kernels
-  return (long long)d.M * d.lda < (1ll << 29) && ((long long)d.N + 512) * d.ldw < (1ll << 29) && d.sy == 1;
+  // (input span: images x Hi x Wi pixels -- more than the M output rows when the walk over the input is strided)
+  const long long imgs = d.Hq * d.Wq > 0 ? (d.M + (long long)d.Hq * d.Wq - 1) / ((long long)d.Hq * d.Wq) : 1;
+  const long long in_elems = (d.Hi > 1 || d.ntaps > 1 ? imgs * d.Hi * d.Wi : (long long)d.M) * d.lda;
+  static const bool strided_ok = getenv("DMX_NO_GLDS_STRIDED") == nullptr;
+  return in_elems < (1ll << 29) && (long long)d.M * d.lda < (1ll << 29) && ((long long)d.N + 512) * d.ldw < (1ll << 29) &&
+         (d.sy == 1 || strided_ok);
 }
 int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   g_last_cfg = cfg;

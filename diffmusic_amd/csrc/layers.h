@@ -64,6 +64,10 @@ struct ConvLayer {
   std::vector<std::vector<int>> wf_taps;  // tap index list per phase (transposed)
   act_t* wb = nullptr;             // dgrad weights
   float* bias = nullptr;            // fp32 [Cop]
+  // nearest x2 upsampling folded into a 3x3 convolution (pack_layer_up2x): four 2x2-tap matrices, one per output parity class,
+  // with the weights of the taps that read the same low-resolution pixel summed; and their joint dgrad as one 4x4-tap stride-2 matrix
+  std::vector<act_t*> wup;
+  act_t* wup_b = nullptr;
   int ntaps() const { return kh * kw; }
 };
 
@@ -96,6 +100,11 @@ int conv_fwd_1d_desc(const ConvLayer& L, const act_t* in, void* out, int B, int 
 int conv_bwd_1d_desc(const ConvLayer& L, const act_t* dout, void* din, int B, int Ti, const Epi& e, GemmDesc& d);
 int conv_pair_run(const GemmDesc& a, const GemmDesc& b, hipStream_t st);
 int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
+// conv3x3(pad 1)(nearest_upsample_x2(in)) without the upsampled tensor: in (B, Hi, Wi, Cip) -> out (B, 2Hi, 2Wi, Cop), and its dgrad
+// dout (B, 2Hi, 2Wi, Cop) -> din (B, Hi, Wi, Cip) (the gradient w.r.t. the LOW-resolution input, upsample backward included)
+int pack_layer_up2x(ParamStore& ps, ConvLayer& L, hipStream_t st);
+int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
+int conv_up2x_bwd(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 int conv_bwd_2d(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 // plain (batched) NT GEMM: C[z] = alpha * A[z] (M,K; lda) * Bm[z]^T (N,K; ldb)  (+ epilogue)
 struct GemmBatch { int Z = 1, Zi = 1; long long sAo = 0, sAi = 0, sBo = 0, sBi = 0, sCo = 0, sCi = 0; };

@@ -83,6 +83,77 @@ static act_t* pack(ParamStore& ps, const float* src, int Np, int Nreal, int T, i
   return dst;
 }
 
+// packed[n][t][c] = sum over the (<= 4) source taps listed for packed tap t of src[n][c][tap]  (fp32 sum, one rounding)
+struct PackSumTaps { int idx[DMX_MAX_TAPS][4]; };
+__global__ void pack_weight_sum_kernel(const float* __restrict__ src, act_t* __restrict__ dst, int Np, int Nreal, int T, int Cp,
+                                       int Creal, long long sn, long long sc, long long st, PackSumTaps taps) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)Np * T * Cp;
+  if (idx >= total) return;
+  const int c = (int)(idx % Cp);
+  const int t = (int)((idx / Cp) % T);
+  const int n = (int)(idx / ((long long)Cp * T));
+  float v = 0.f;
+  if (n < Nreal && c < Creal)
+    for (int q = 0; q < 4; ++q) if (taps.idx[t][q] >= 0) v += src[n * sn + c * sc + taps.idx[t][q] * st];
+  dst[idx] = f2a(v);
+}
+
+// Nearest x2 upsampling followed by a 3x3 / pad 1 convolution reads, for an output pixel of parity (py, px), only a 2x2
+// neighbourhood of the low-resolution image: rows {y-1, y} (py = 0: upsampled rows 2y-1 | 2y, 2y+1) or {y, y+1} (py = 1: 2y, 2y+1 |
+// 2y+2), likewise in x.  Summing the 3x3 weights that land on the same low-resolution pixel gives four 2x2-tap convolutions
+// (4/9 of the multiply-adds, no upsampled tensor in HBM); zero padding of the upsampled image maps onto zero padding of the
+// low-resolution one.  rows_of(p, t): the kernel rows summed into tap t of parity p.
+static void up2x_rows(int p, int t, int (&k)[2]) {
+  k[0] = k[1] = -1;
+  if (p == 0) { if (t == 0) k[0] = 0; else { k[0] = 1; k[1] = 2; } }
+  else { if (t == 0) { k[0] = 0; k[1] = 1; } else k[0] = 2; }
+}
+static int up2x_delta(int p, int t) { return p == 0 ? t - 1 : t; }      // low-resolution offset of tap t at parity p
+
+int pack_layer_up2x(ParamStore& ps, ConvLayer& L, hipStream_t st) {
+  if (L.transposed || L.kh != 3 || L.kw != 3 || L.stride != 1 || L.pad_h != 1 || L.pad_w != 1) return DMX_ERR_SHAPE;
+  const float* w = ps.dev(L.w_id);               // W[Co][Ci][3][3]
+  const int T9 = 9;
+  L.wup.clear();
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      PackSumTaps pt;
+      for (auto& r : pt.idx) for (int& v : r) v = -1;
+      for (int ty = 0; ty < 2; ++ty)
+        for (int tx = 0; tx < 2; ++tx) {
+          int ky[2], kx[2], n = 0;
+          up2x_rows(py, ty, ky); up2x_rows(px, tx, kx);
+          for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (ky[a] >= 0 && kx[b] >= 0) pt.idx[ty * 2 + tx][n++] = ky[a] * 3 + kx[b];
+        }
+      const long long total = (long long)L.Cop * 4 * L.Cip;
+      act_t* dst = (act_t*)ps.dalloc(total * 2);
+      if (!dst) return DMX_ERR_PARAM;
+      hipLaunchKernelGGL(pack_weight_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, dst, L.Cop, L.Co, 4, L.Cip, L.Ci,
+                         (long long)L.Ci * T9, (long long)T9, 1ll, pt);
+      L.wup.push_back(dst);
+    }
+  if (L.need_bwd) {
+    // joint dgrad: din[y, x] = sum over (py, ty, px, tx) of Wsum^T . dout[2 (y - dy) + py, 2 (x - dx) + px]: 16 taps at offsets
+    // py - 2 dy in {2, 0, 1, -1} of a stride-2 walk over dout; packed [Cip][16][Cop]
+    PackSumTaps pt;
+    for (auto& r : pt.idx) for (int& v : r) v = -1;
+    for (int py = 0; py < 2; ++py) for (int ty = 0; ty < 2; ++ty)
+      for (int px = 0; px < 2; ++px) for (int tx = 0; tx < 2; ++tx) {
+        int ky[2], kx[2], n = 0;
+        up2x_rows(py, ty, ky); up2x_rows(px, tx, kx);
+        const int t = (py * 2 + ty) * 4 + (px * 2 + tx);
+        for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) if (ky[a] >= 0 && kx[b] >= 0) pt.idx[t][n++] = ky[a] * 3 + kx[b];
+      }
+    const long long total = (long long)L.Cip * 16 * L.Cop;
+    L.wup_b = (act_t*)ps.dalloc(total * 2);
+    if (!L.wup_b) return DMX_ERR_PARAM;
+    hipLaunchKernelGGL(pack_weight_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, L.wup_b, L.Cip, L.Ci, 16, L.Cop, L.Co,
+                       (long long)T9, (long long)L.Ci * T9, 1ll, pt);
+  }
+  return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+}
+
 static ConvLayer base_layer(ParamStore& ps, const std::string& prefix, std::vector<int> wshape, int Co, bool bias) {
   ConvLayer L;
   L.w_id = ps.add(prefix + ".weight", wshape);
@@ -257,6 +328,46 @@ int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, i
     for (int kx = 0; kx < L.kw; ++kx) {
       d.tdy[ky * L.kw + kx] = (signed char)(ky - L.pad_h);
       d.tdx[ky * L.kw + kx] = (signed char)(kx - L.pad_w);
+    }
+  return dmx_gemm_launch(d, st);
+}
+
+int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {
+  if (L.wup.size() != 4) { dmx_set_error("layer has no upsample-folded weights"); return DMX_ERR_STATE; }
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      GemmDesc d;
+      init_desc(d, e);
+      if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
+      d.A = in; d.Hi = Hi; d.Wi = Wi; d.Ci = L.Cip; d.lda = L.Cip;
+      d.W = L.wup[py * 2 + px]; d.ntaps = 4; d.K = 4 * L.Cip; d.ldw = d.K;
+      d.N = L.Cop; d.Hq = Hi; d.Wq = Wi; d.M = B * Hi * Wi;
+      set_out(d, out, 2 * Hi, 2 * Wi, L.Cop);
+      d.osy = d.osx = 2; d.ooy = py; d.oox = px;
+      for (int ty = 0; ty < 2; ++ty)
+        for (int tx = 0; tx < 2; ++tx) {
+          d.tdy[ty * 2 + tx] = (signed char)up2x_delta(py, ty);
+          d.tdx[ty * 2 + tx] = (signed char)up2x_delta(px, tx);
+        }
+      const int rc = dmx_gemm_launch(d, st);
+      if (rc != DMX_OK) return rc;
+    }
+  return DMX_OK;
+}
+
+int conv_up2x_bwd(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {
+  if (!L.wup_b) { dmx_set_error("layer has no upsample-folded dgrad weights"); return DMX_ERR_STATE; }
+  GemmDesc d;
+  init_desc(d, e);
+  d.A = dout; d.Hi = 2 * Hi; d.Wi = 2 * Wi; d.Ci = L.Cop; d.lda = L.Cop;
+  d.W = L.wup_b; d.ntaps = 16; d.K = 16 * L.Cop; d.ldw = d.K;
+  d.N = L.Cip; d.Hq = Hi; d.Wq = Wi; d.sy = d.sx = 2; d.M = B * Hi * Wi;
+  set_out(d, din, Hi, Wi, L.Cip);
+  for (int py = 0; py < 2; ++py) for (int ty = 0; ty < 2; ++ty)
+    for (int px = 0; px < 2; ++px) for (int tx = 0; tx < 2; ++tx) {
+      const int t = (py * 2 + ty) * 4 + (px * 2 + tx);
+      d.tdy[t] = (signed char)(py - 2 * up2x_delta(py, ty));
+      d.tdx[t] = (signed char)(px - 2 * up2x_delta(px, tx));
     }
   return dmx_gemm_launch(d, st);
 }

@@ -16,6 +16,7 @@ struct VaeDecoder : Model {
   std::vector<int> up_ch;
   float* gn_partial = nullptr;
   int Cmid = 0;
+  bool up2x = true;            // fold the nearest x2 upsampling into the 3x3 convolution that follows it
   // tape
   int B = 0, h = 0, w = 0;
   bool have_tape = false;
@@ -69,7 +70,8 @@ struct VaeDecoder : Model {
     CTRY(pack_layer(ps, to_v, st));
     CTRY(pack_layer(ps, to_out, st));
     for (auto& rs : up_res) for (auto& r : rs) CTRY(r.pack(ps, st));
-    for (auto& l : up_conv) CTRY(pack_layer(ps, l, st));
+    for (auto& l : up_conv) { CTRY(pack_layer(ps, l, st)); CTRY(pack_layer_up2x(ps, l, st)); }
+    up2x = getenv("DMX_NO_UP2X") == nullptr;
     return DMX_OK;
   }
 
@@ -135,10 +137,16 @@ struct VaeDecoder : Model {
         const size_t P2 = (size_t)H2 * W2;
         y = A.bf(B * P2 * ch);
         const size_t mk = A.mark();
-        act_t* u = A.bf(B * P2 * ch);
-        CRUN(dmx_upsample_nearest(x, u, B, H, W, H2, W2, ch, st));
         Epi e;
-        CRUN(conv_fwd_2d(up_conv[i], u, y, B, H2, W2, e, st));
+        if (up2x) {
+          // nearest x2 + conv3x3 as four 2x2-tap convolutions of the low-resolution tensor (one per output parity): 4/9 of the
+          // multiply-adds and no upsampled tensor (Upsample2D, diffusers 0.31.0 semantics)
+          CRUN(conv_up2x_fwd(up_conv[i], x, y, B, H, W, e, st));
+        } else {
+          act_t* u = A.bf(B * P2 * ch);
+          CRUN(dmx_upsample_nearest(x, u, B, H, W, H2, W2, ch, st));
+          CRUN(conv_fwd_2d(up_conv[i], u, y, B, H2, W2, e, st));
+        }
         A.release(mk);
         x = y; H = H2; W = W2; P = P2;
       }
@@ -183,9 +191,13 @@ struct VaeDecoder : Model {
         const int Hl = H / 2, Wl = W / 2;
         act_t* gl = A.bf((size_t)B * Hl * Wl * ch);
         const size_t mk = A.mark();
-        act_t* gu = A.bf(B * P * ch);
-        CRUN(conv_bwd_2d(up_conv[i], g, gu, B, H, W, e, st));
-        CRUN(dmx_upsample2x_bwd(gu, gl, B, Hl, Wl, ch, st));
+        if (up2x) {
+          CRUN(conv_up2x_bwd(up_conv[i], g, gl, B, Hl, Wl, e, st));      // dgrad of the folded convolution: one 4x4-tap stride-2 launch
+        } else {
+          act_t* gu = A.bf(B * P * ch);
+          CRUN(conv_bwd_2d(up_conv[i], g, gu, B, H, W, e, st));
+          CRUN(dmx_upsample2x_bwd(gu, gl, B, Hl, Wl, ch, st));
+        }
         A.release(mk);
         g = gl; H = Hl; W = Wl; P = (size_t)H * W;
       }
