@@ -11,9 +11,9 @@ for r in csv.DictReader(open(sys.argv[1])):
     s["ms"] += float(r["ms"]); s["n"] += 1
 saved = 0.0
 for (M, N, K, Z), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
-    if s["ms"] < 0.25 or M < 30000 or Z > 1: continue
+    if s["ms"] < 0.15 or M < 30000 or Z > 1: continue
     res = {}
-    for c in (1, 2, 7, 8, 9, 10, 11):
+    for c in (1, 2, 7, 8, 9, 10, 11, 19):
         if c in (1, 7, 8) and N % 256: continue
         try: res[c] = time_cfg(M, N, K, Z, s["taps"], s["flags"], c, 4)
         except Exception: pass
