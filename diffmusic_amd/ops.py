@@ -46,6 +46,10 @@ def enabled():
     global _usable
     if not USE_TORCH_OPS:
         return False
+    if os.environ.get("DMX_LIB_PATH"):
+        # a dev A/B build of libdiffmusic_hip.so is selected for the ctypes binding; the op library is linked (rpath) against the
+        # in-tree one, so going through it would silently measure the other library's kernels
+        return False
     if _usable is None:
         try:
             load()
