@@ -91,6 +91,9 @@ enum {
   EPI_MASKBITS = 1024, // like EPI_MASK, but the mask source is a SIGN-BIT tensor XB: byte [row][n / 8], bit (n & 7) set <=> x > 0
   EPI_BITS2 = 2048,    // also write the sign bits (v > 0) of the stored value to B2 (same layout): the leaky-relu' mask of the
                        // backward sweep at 1/16 of the bytes of the 16-bit tensor (HiFi-GAN tape)
+  EPI_GEGLU = 8192,    // GEGLU of a feed-forward's first projection fused into its epilogue: the weight rows are packed in blocks of
+                       // 32 = [16 value rows | their 16 gate rows], so accumulator fragments 2t / 2t + 1 of a wave hold value and gate of
+                       // the same 16 channels: out[row, 16 t' + c] = (v + bias) * gelu_erf(g + bias), N / 2 output columns (ld = ldc)
   EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
                        // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };

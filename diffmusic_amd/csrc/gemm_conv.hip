@@ -507,6 +507,7 @@ int launch_glds(const GemmDesc& d, hipStream_t stream) {
     if constexpr (BM == 256 && BN == 256) return launch_glds_t<BM, BN, WM, WN, NSTAGE, 2>(d, stream);
     else return DMX_ERR_SHAPE;
   }
+  if (d.flags & EPI_GEGLU) return launch_glds_t<BM, BN, WM, WN, NSTAGE, 3>(d, stream);
   return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_glds_t<BM, BN, WM, WN, NSTAGE, 1>(d, stream)
                                                 : launch_glds_t<BM, BN, WM, WN, NSTAGE, 0>(d, stream);
 }
@@ -529,6 +530,10 @@ int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmDesc& d, hipStream_t stream) {
   if (d.flags & EPI_SOFTBWD) return DMX_ERR_SHAPE;
+  if (d.flags & EPI_GEGLU) {
+    if constexpr ((BN / WN) % 32 == 0) return launch_cfg_t<BM, BN, WM, WN, 3>(d, stream);
+    else return DMX_ERR_SHAPE;
+  }
   return (d.flags & (EPI_MASKBITS | EPI_BITS2)) ? launch_cfg_t<BM, BN, WM, WN, 1>(d, stream) : launch_cfg_t<BM, BN, WM, WN, 0>(d, stream);
 }
 
@@ -749,7 +754,7 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
 int splitk_plan(const GemmDesc& d, int* tile) {
   static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
   if (off || !g_splitk_ws || d.Z != 1 || !glds_ok(d)) return 1;
-  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD)) return 1;
+  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_GEGLU)) return 1;
   if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
   if ((d.N & 7) || (d.ldc & 3)) return 1;
   const int nk = (d.K + BK - 1) / BK;
@@ -824,6 +829,11 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
   if (d.flags & EPI_SOFTBWD) {
     // fused softmax backward: 16-bit output through the LDS-staged epilogue, P tile as X, per-row delta in rowbias, Zi == 1
     if ((d.flags & ~(EPI_SOFTBWD)) || ((d.N | d.ldc | d.ldx) & 7) || !d.X || !d.rowbias || d.Zi != 1 || d.ntaps != 1) return DMX_ERR_SHAPE;
+    if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return DMX_ERR_SHAPE;
+  }
+  if (d.flags & EPI_GEGLU) {
+    // fused GEGLU: bias only, 16-bit half-width output through the LDS-staged epilogue, interleaved blocks of 32 weight rows
+    if ((d.flags & ~(EPI_GEGLU | EPI_BIAS)) || (d.N & 31) || (d.ldc & 7) || d.ldc < d.N / 2 || d.alpha != 1.f) return DMX_ERR_SHAPE;
     if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return DMX_ERR_SHAPE;
   }
   if (d.flags & (EPI_MASKBITS | EPI_BITS2)) {

@@ -120,6 +120,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   // its LDS slab) -- the residual tensor is then not read from HBM again
   constexpr bool BITS = EM == 1;          // sign-bit tape paths
   constexpr bool SOFT = EM == 2;          // fused softmax backward (EPI_SOFTBWD)
+  constexpr bool GEGLU = EM == 3;         // value * gelu(gate) of interleaved fragment pairs, half-width output (EPI_GEGLU)
+  static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs accumulator fragments");
   constexpr int CH = EpiChunk<FM>::CH;
   constexpr int IB = EpiChunk<FM>::IB;
   constexpr int TNB = FN * 32;            // bytes per tile row
@@ -200,13 +202,15 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       DMX_LDS_SYNC();
     };
     auto stage_out = [&](act_t* G, int ld, auto&& f) {
+      // (GEGLU: only the even fragments carry results; they are packed into the left half of the tile rows and leave as N / 2 columns)
+      constexpr int JS = GEGLU ? 2 : 1;
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
+        for (int j = 0; j < FN; j += JS) {
           float o[4];
           f(acc[h * IB + ii][j], o);
-          *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + (j * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
+          *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + ((j / JS) * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
         }
       DMX_LDS_SYNC();
       constexpr int HN = NIT > 4 ? NIT / 2 : NIT;      // row-major read / store in groups of <= 4 instructions (register pressure)
@@ -218,9 +222,11 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       // (no explicit wait here: the stores depend on v through registers, and a later LDS write of this wave cannot pass
       //  these reads -- LDS operations of one wave complete in order.  A "memory"-clobbering asm at this point made hipcc
       //  keep v[] in scratch: every output byte was written twice.)
+      const int ocol = GEGLU ? (n0 >> 1) + cch * 8 : ncol;
+      const bool ocol_ok = GEGLU ? (cch < CPR / 2 && ocol < (p.N >> 1)) : col_ok;
 #pragma unroll
       for (int it = 0; it < HN; ++it) {
-        if (orows[g0 + it] >= 0 && col_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ncol) = v[it];
+        if (orows[g0 + it] >= 0 && ocol_ok) *reinterpret_cast<uint4*>(G + coff + (long long)orows[g0 + it] * ld + ocol) = v[it];
       }
       }
     };
@@ -308,6 +314,18 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           }
         }
       }
+    }
+    if constexpr (GEGLU) {
+      // value * gelu_erf(gate): fragment j holds the values, j + 1 the gates of the same 16 channels (fp32, before any rounding)
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii)
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          f32x4& a = acc[h * IB + ii][j];
+          const f32x4& g = acc[h * IB + ii][j + 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) a[e] *= 0.5f * g[e] * (1.f + erff(g[e] * 0.70710678118654752f));
+        }
     }
     if ((flags & EPI_RESID) && use_rpre) {
       const float is = (flags & EPI_RESID_INV) ? p.resid_inv_slope : 1.f;

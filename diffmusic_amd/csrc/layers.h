@@ -58,6 +58,8 @@ struct ConvLayer {
   int kh = 1, kw = 1, stride = 1, dil = 1, pad_h = 0, pad_w = 0;
   bool transposed = false;  // ConvTranspose1d (weight layout Cin,Cout,k)
   bool has_bias = true, need_bwd = false;
+  bool geglu = false;       // linear layer whose output is [values | gates]: rows packed in blocks of 32 = [16 values | their 16 gates]
+                            // (bias likewise) so that the GEMM epilogue can apply GEGLU (EPI_GEGLU); forward only
   int w_id = -1, b_id = -1;
   // packed
   std::vector<act_t*> wf;          // forward weights (one per output phase for transposed)

@@ -54,32 +54,39 @@ void ParamStore::free_all() {
 
 // ------------------------------------------------------------------------------ packing
 struct PackTaps { int idx[DMX_MAX_TAPS]; };
+// packed row p of a GEGLU projection with `half` value rows followed by `half` gate rows: blocks of 32 = [16 values | their 16 gates]
+__host__ __device__ inline int geglu_src_row(int p, int half) {
+  const int b = p >> 5, q = p & 31;
+  return q < 16 ? 16 * b + q : half + 16 * b + (q - 16);
+}
 __global__ void pack_weight_kernel(const float* __restrict__ src, act_t* __restrict__ dst, int Np, int Nreal, int T, int Cp,
-                                   int Creal, long long sn, long long sc, long long st, PackTaps taps) {
+                                   int Creal, long long sn, long long sc, long long st, PackTaps taps, int geglu_half) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)Np * T * Cp;
   if (idx >= total) return;
   const int c = (int)(idx % Cp);
   const int t = (int)((idx / Cp) % T);
-  const int n = (int)(idx / ((long long)Cp * T));
+  int n = (int)(idx / ((long long)Cp * T));
+  if (geglu_half > 0) n = geglu_src_row(n, geglu_half);
   float v = 0.f;
   if (n < Nreal && c < Creal && taps.idx[t] >= 0) v = src[n * sn + c * sc + taps.idx[t] * st];
   dst[idx] = f2a(v);
 }
-__global__ void pad_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np) {
+__global__ void pad_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int np, int geglu_half) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < np) dst[i] = (src && i < n) ? src[i] : 0.f;
+  const int s = geglu_half > 0 ? geglu_src_row(i, geglu_half) : i;
+  if (i < np) dst[i] = (src && s < n) ? src[s] : 0.f;
 }
 
 static act_t* pack(ParamStore& ps, const float* src, int Np, int Nreal, int T, int Cp, int Creal, long long sn, long long sc,
-                    long long st_, const std::vector<int>& tapidx, hipStream_t st) {
+                    long long st_, const std::vector<int>& tapidx, hipStream_t st, int geglu_half = 0) {
   const long long total = (long long)Np * T * Cp;
   act_t* dst = (act_t*)ps.dalloc(total * 2);
   if (!dst) return nullptr;
   PackTaps pt;
   for (int i = 0; i < DMX_MAX_TAPS; ++i) pt.idx[i] = i < (int)tapidx.size() ? tapidx[i] : -1;
   hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, Np, Nreal, T, Cp,
-                     Creal, sn, sc, st_, pt);
+                     Creal, sn, sc, st_, pt, geglu_half);
   return dst;
 }
 
@@ -199,9 +206,14 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
   if (T > DMX_MAX_TAPS) { dmx_set_error("too many taps"); return DMX_ERR_SHAPE; }
   std::vector<int> all(T);
   for (int i = 0; i < T; ++i) all[i] = i;
+  int gh = 0;
+  if (L.geglu) {
+    if (L.transposed || T != 1 || L.need_bwd || (L.Co & 31) || L.Cop != L.Co) { dmx_set_error("GEGLU packing needs a forward-only linear layer with Cout %% 32 == 0"); return DMX_ERR_SHAPE; }
+    gh = L.Co / 2;
+  }
   if (!L.transposed) {
     // W[Co][Ci][T]
-    L.wf.push_back(pack(ps, w, L.Cop, L.Co, T, L.Cip, L.Ci, (long long)L.Ci * T, T, 1, all, st));
+    L.wf.push_back(pack(ps, w, L.Cop, L.Co, T, L.Cip, L.Ci, (long long)L.Ci * T, T, 1, all, st, gh));
     if (L.need_bwd) L.wb = pack(ps, w, L.Cip, L.Ci, T, L.Cop, L.Co, T, (long long)L.Ci * T, 1, all, st);
   } else {
     // W[Ci][Co][k]; one packed matrix per output phase
@@ -217,7 +229,7 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
   }
   L.bias = (float*)ps.dalloc(L.Cop * sizeof(float));
   hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(L.Cop, 256)), dim3(256), 0, st, L.has_bias ? ps.dev(L.b_id) : (const float*)nullptr,
-                     L.bias, L.Co, L.Cop);
+                     L.bias, L.Co, L.Cop, gh);
   for (act_t* pw : L.wf) if (!pw) return DMX_ERR_PARAM;
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
@@ -412,6 +424,7 @@ int linear_fwd(const ConvLayer& L, const act_t* in, int lda, void* out, int ldc,
   d.W = L.wf[0]; d.ntaps = 1; d.K = L.Cip; d.ldw = L.Cip;
   d.N = L.Cop; d.Hq = 1; d.Wq = (int)rows; d.M = (int)rows;
   set_out(d, out, 1, (int)rows, ldc);
+  if (L.geglu) d.flags |= EPI_GEGLU;          // out is (rows, Cop / 2): value * gelu(gate), applied in the epilogue
   return dmx_gemm_launch(d, st);
 }
 int linear_bwd(const ConvLayer& L, const act_t* dout, int lda, void* din, int ldc, long long rows, const Epi& e, hipStream_t st) {

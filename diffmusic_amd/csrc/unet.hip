@@ -92,6 +92,7 @@ struct Transformer2D {
     attn2.build(ps, tb + ".attn2", ch, cross > 0 ? cross : ch, heads);
     ln3.build(ps, tb + ".norm3", ch);
     ff1 = make_linear(ps, tb + ".ff.net.0.proj", ch, ch * 8, true, false);
+    ff1.geglu = ((ch * 8) % 32 == 0) && getenv("DMX_NO_GEGLU_FUSE") == nullptr;     // GEGLU in the projection's epilogue (no 8C-wide tensor)
     ff2 = make_linear(ps, tb + ".ff.net.2", ch * 4, ch, true, false);
     proj_out = make_conv2d(ps, pre + ".proj_out", ch, ch, 1, 1, 0, false);
   }
@@ -123,10 +124,14 @@ struct Transformer2D {
     CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
     {
       const size_t mk2 = A.mark();
-      act_t* f = A.bf((size_t)B * N * C * 8);
       act_t* gg = A.bf((size_t)B * N * C * 4);
-      CRUN(linear_fwd(ff1, l, C, f, C * 8, (long long)B * N, e, cx.st));
-      CRUN(dmx_geglu(f, gg, (long long)B * N, C * 4, cx.st));
+      if (ff1.geglu) {
+        CRUN(linear_fwd(ff1, l, C, gg, C * 4, (long long)B * N, e, cx.st));       // [values | gates] -> values * gelu(gates) in the epilogue
+      } else {
+        act_t* f = A.bf((size_t)B * N * C * 8);
+        CRUN(linear_fwd(ff1, l, C, f, C * 8, (long long)B * N, e, cx.st));
+        CRUN(dmx_geglu(f, gg, (long long)B * N, C * 4, cx.st));
+      }
       Epi er; er.flags = EPI_RESID; er.R = hbuf;
       CRUN(linear_fwd(ff2, gg, C * 4, hbuf, C, (long long)B * N, er, cx.st));
       A.release(mk2);
