@@ -157,6 +157,7 @@ struct UNet : Model {
   std::vector<Block> down, up;
   Resnet2D mid_r0, mid_r1;
   float* gn_partial = nullptr;
+  bool up2x = true;
   int temb_ch = 0, tdim = 0, napl = 1;
   int cross_dims[4] = {-1, 0, 0, 0};
   std::vector<Transformer2D> mid_attns;
@@ -250,6 +251,8 @@ struct UNet : Model {
         for (auto& a : b.attn) CTRY(a.pack(ps, st));
         if (b.has_sampler) CTRY(pack_layer(ps, b.sampler, st));
       }
+    for (auto& b : up) if (b.has_sampler) CTRY(pack_layer_up2x(ps, b.sampler, st));      // exact x2 upsamplers run folded (layers.hip)
+    up2x = getenv("DMX_NO_UP2X") == nullptr;
     CTRY(mid_r0.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
     for (auto& a : mid_attns) CTRY(a.pack(ps, st));
     // fused time-embedding projection
@@ -429,9 +432,14 @@ struct UNet : Model {
         const int H2 = nxt.H, W2 = nxt.W;
         act_t* y = A.bf((size_t)B * H2 * W2 * b.ch);
         const size_t mk = A.mark();
-        act_t* u = A.bf((size_t)B * H2 * W2 * b.ch);
-        CRUN(dmx_upsample_nearest(cur, u, B, H, W, H2, W2, b.ch, st));
-        CRUN(conv_fwd_2d(b.sampler, u, y, B, H2, W2, e, st));
+        if (up2x && H2 == 2 * H && W2 == 2 * W) {
+          // exact x2 (the other levels interpolate to the skip tensor's odd size): nearest x2 + conv3x3 as four parity convolutions
+          CRUN(conv_up2x_fwd(b.sampler, cur, y, B, H, W, e, st));
+        } else {
+          act_t* u = A.bf((size_t)B * H2 * W2 * b.ch);
+          CRUN(dmx_upsample_nearest(cur, u, B, H, W, H2, W2, b.ch, st));
+          CRUN(conv_fwd_2d(b.sampler, u, y, B, H2, W2, e, st));
+        }
         A.release(mk);
         cur = y; H = H2; W = W2;
       }
