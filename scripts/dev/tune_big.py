@@ -11,7 +11,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     s["ms"] += float(r["ms"]); s["n"] += 1
 saved = 0.0
 for (M, N, K, Z), s in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"]):
-    if s["ms"] < 0.15 or M < 30000 or Z > 1: continue
+    if s["ms"] < float(sys.argv[2] if len(sys.argv) > 2 else 0.15) or M < int(sys.argv[3] if len(sys.argv) > 3 else 30000) or Z > 1: continue
     res = {}
     for c in (1, 2, 7, 8, 9, 10, 11, 19):
         if c in (1, 7, 8) and N % 256: continue
