@@ -46,14 +46,21 @@ struct AttnLayer {
     return DMX_OK;
   }
   // hres += to_out(attn(l, ctx)) ; l (B,N,C) normalised input, ctx (B,Nc,Cc) or nullptr (self)
-  int fwd(Ctx& cx, const act_t* l, const act_t* ctx, int Nc, act_t* hres, int B, int N, const float* colbias) const {
+  // kv_pre / ldkv: this layer's [k | v] slice (2C columns, row stride ldkv) of a projection of the context computed once per forward
+  // for all cross-attention layers (UNet::ctxkv); nullptr: project here
+  int fwd(Ctx& cx, const act_t* l, const act_t* ctx, int Nc, act_t* hres, int B, int N, const float* colbias,
+          const act_t* kv_pre = nullptr, int ldkv = 0) const {
     Arena& A = *cx.arena;
     const size_t mk = A.mark();
     const act_t* kv_in = ctx ? ctx : l;
     const int Nk = ctx ? Nc : N;
     act_t* o = A.bf((size_t)B * N * C);
     Epi e;
-    if (!ctx && fused) {
+    if (ctx && ldkv > 0) {
+      act_t* q = A.bf((size_t)B * N * C);
+      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
+      CTRY(attention_core(cx, q, kv_pre, kv_pre + C, o, B, N, Nk, C, heads, nullptr, colbias, C, ldkv, ldkv));
+    } else if (!ctx && fused) {
       // self-attention: q | k | v come out of one GEMM (N = 3C) and are consumed as strided slices
       act_t* qkv = A.bf((size_t)B * N * 3 * C);
       CRUN(linear_fwd(to_qkv, l, to_q.Cip, qkv, 3 * C, (long long)B * N, e, cx.st));
@@ -105,7 +112,7 @@ struct Transformer2D {
   }
   // x (B,H,W,C) -> out (B,H,W,C); out may not alias x
   int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* ctx = nullptr, int Nc = 0,
-          const float* colbias = nullptr) const {
+          const float* colbias = nullptr, const act_t* kv_pre = nullptr, int ldkv = 0) const {
     Arena& A = *cx.arena;
     const int N = H * W;
     const size_t mk = A.mark();
@@ -119,7 +126,7 @@ struct Transformer2D {
     CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
     CTRY(attn1.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));
     CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
-    if (cross > 0) CTRY(attn2.fwd(cx, l, ctx, Nc, hbuf, B, N, colbias));
+    if (cross > 0) CTRY(attn2.fwd(cx, l, ctx, Nc, hbuf, B, N, colbias, kv_pre, ldkv));
     else CTRY(attn2.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));   // encoder_hidden_states=None -> self-attention
     CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
     {
@@ -229,6 +236,17 @@ struct UNet : Model {
     splitk_ws = (float*)ps.dalloc(kSplitKBytes);        // fp32 partial tiles of the split-K low-resolution convolutions
   }
 
+  // the to_k / to_v projections of every cross-attention layer that attends context k, stacked along N: the context is the same for all
+  // of them, so ONE (B * tokens) x (sum 2C) GEMM per context and forward replaces two M = 64 ... 256 launches per cross-attention layer
+  // (AudioLDM2: 64 launches per forward); each layer takes its [k | v] slice with the stacked row stride
+  struct CtxKV { ConvLayer all; std::vector<const AttnLayer*> order; std::vector<int> off; int total = 0; bool ok = false; };
+  CtxKV ctxkv[2];
+  const act_t* ctx_kv[2] = {nullptr, nullptr};
+  bool ctx_kv_on[2] = {false, false};
+  int ctxkv_slot(int k, const AttnLayer* a) const {
+    for (size_t i = 0; i < ctxkv[k].order.size(); ++i) if (ctxkv[k].order[i] == a) return ctxkv[k].off[i];
+    return -1;
+  }
   static constexpr size_t kSplitKBytes = 64u << 20;
   float* splitk_ws = nullptr;
   // every resnet's time_emb_proj stacked along N: one (B x temb_ch) x (sum Cout) GEMM per forward instead of 22 M = 16 launches
@@ -255,6 +273,46 @@ struct UNet : Model {
     up2x = getenv("DMX_NO_UP2X") == nullptr;
     CTRY(mid_r0.pack(ps, st)); CTRY(mid_r1.pack(ps, st));
     for (auto& a : mid_attns) CTRY(a.pack(ps, st));
+    // stacked context projections (cross-attention k / v)
+    for (int k = 0; k < 2; ++k) { ctxkv[k].order.clear(); ctxkv[k].off.clear(); ctxkv[k].total = 0; ctxkv[k].ok = false; }
+    if (getenv("DMX_NO_CTXKV_FUSE") == nullptr) {
+      auto visit = [&](std::vector<Transformer2D>& tfs) {
+        for (size_t i = 0; i < tfs.size(); ++i) {
+          if (tfs[i].cross <= 0) continue;
+          int k = 0;
+          for (int q = 0; q < (int)(i % napl); ++q) if (cross_dims[q] > 0) ++k;       // which context this transformer of its layer attends
+          if (k >= 2) continue;
+          ctxkv[k].order.push_back(&tfs[i].attn2);
+          ctxkv[k].off.push_back(ctxkv[k].total);
+          ctxkv[k].total += 2 * tfs[i].attn2.C;
+        }
+      };
+      for (auto& b : down) visit(b.attn);
+      visit(mid_attns);
+      for (auto& b : up) visit(b.attn);
+      for (int k = 0; k < 2; ++k) {
+        CtxKV& s = ctxkv[k];
+        if (s.order.empty()) continue;
+        const int Cip = s.order[0]->to_k.Cip;
+        bool same = true;
+        for (const AttnLayer* a : s.order) same = same && a->to_k.Cip == Cip && a->to_v.Cip == Cip && a->to_k.Cop == a->C && a->to_v.Cop == a->C && !a->to_k.has_bias && !a->to_v.has_bias;
+        if (!same) continue;
+        act_t* w = (act_t*)ps.dalloc((size_t)s.total * Cip * sizeof(act_t));
+        if (!w) return DMX_ERR_PARAM;
+        for (size_t i = 0; i < s.order.size(); ++i) {
+          const AttnLayer* a = s.order[i];
+          const size_t one = (size_t)a->C * Cip * sizeof(act_t);
+          (void)hipMemcpyAsync((char*)w + (size_t)s.off[i] * Cip * sizeof(act_t), a->to_k.wf[0], one, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync((char*)w + (size_t)s.off[i] * Cip * sizeof(act_t) + one, a->to_v.wf[0], one, hipMemcpyDeviceToDevice, st);
+        }
+        s.all = s.order[0]->to_k;
+        s.all.Co = s.all.Cop = s.total;
+        s.all.wf.assign(1, w);
+        s.all.has_bias = false;
+        s.all.bias = nullptr;
+        s.ok = true;
+      }
+    }
     // fused time-embedding projection
     temb_order.clear(); temb_off.clear(); temb_total = 0;
     for (auto& b : down) for (auto& r : b.res) if (r.has_temb) temb_order.push_back(&r);
@@ -296,7 +354,13 @@ struct UNet : Model {
     for (int q = 0; q < napl; ++q) {
       act_t* dst = ((napl - 1 - q) & 1) ? tmp : out;          // last one lands in `out`
       const bool cross = tf[q].cross > 0;
-      CTRY(tf[q].fwd(cx, src, dst, B, H, W, cross ? ctx_ptr[kctx] : nullptr, cross ? ctx_n[kctx] : 0, cross ? ctx_bias[kctx] : nullptr));
+      const act_t* kvp = nullptr;
+      int ldkv = 0;
+      if (cross && kctx < 2 && ctx_kv_on[kctx]) {
+        const int off = ctxkv_slot(kctx, &tf[q].attn2);
+        if (off >= 0) { kvp = ctx_kv[kctx] + off; ldkv = ctxkv[kctx].total; }
+      }
+      CTRY(tf[q].fwd(cx, src, dst, B, H, W, cross ? ctx_ptr[kctx] : nullptr, cross ? ctx_n[kctx] : 0, cross ? ctx_bias[kctx] : nullptr, kvp, ldkv));
       if (cross) ++kctx;
       src = dst;
     }
@@ -325,6 +389,13 @@ struct UNet : Model {
         act_t* c16 = A.bf((size_t)B * cn[k] * cross_dims[q]);
         CRUN(dmx_f32_to_bf16(cin[k], c16, (long long)B * cn[k] * cross_dims[q], 1.f, st));
         ctx_ptr[k] = c16; ctx_n[k] = cn[k]; ctx_bias[k] = (k == 1) ? bias1 : nullptr;
+        ctx_kv[k] = nullptr; ctx_kv_on[k] = false;
+        if (ctxkv[k].ok) {
+          act_t* kv = A.bf((size_t)B * cn[k] * ctxkv[k].total);
+          Epi ek;
+          CRUN(linear_fwd(ctxkv[k].all, c16, ctxkv[k].all.Cip, kv, ctxkv[k].total, (long long)B * cn[k], ek, st));
+          ctx_kv[k] = kv; ctx_kv_on[k] = true;
+        }
         ++k;
       }
     }
