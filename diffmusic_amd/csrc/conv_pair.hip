@@ -35,6 +35,15 @@ struct PairParams {
   int a_tape_bits_only;                  // forward: the activated intermediate leaves the kernel as sign bits only (a.B2), not as a tensor
 };
 
+#ifdef DMX_PAIR_STAMPS
+// diagnostic build only (scripts/dev/r03_pair_stamps.sh): 100 MHz wall-clock stamps of the phases of the first 4096 workgroups
+__device__ unsigned long long g_pair_stamps[4096 * 8];
+// (kept in registers and written once at the end: a stamp stored on the spot is a global store the next compiler-inserted vmcnt(0) waits for)
+#define DMX_STAMP(i) do { stamp_v[i] = wall_clock64(); } while (0)
+#else
+#define DMX_STAMP(i) do { } while (0)
+#endif
+
 template <int C>
 struct PairCfg {
   // +32 B: a ds_read_b128 lane group is 8 rows at one k-quarter plus 8 other rows at the next (MI355X_MICROARCH.md, LDS);
@@ -93,6 +102,11 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int rg = wave / WN, cg = wave - rg * WN;       // row group (64 intermediate rows) and column group (64 channels) of this wave
+#ifdef DMX_PAIR_STAMPS
+  const int stamp_id = bid;
+  unsigned long long stamp_v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  DMX_STAMP(0);
   {  // XCD-aware remap: neighbouring time tiles (shared halos, same weights) land on the same L2
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -177,6 +191,7 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  DMX_STAMP(1);
 
   f32x4 acc[4][FN];
   auto zero_acc = [&]() {
@@ -296,6 +311,16 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
     // ---- stage A: 256 intermediate rows, row i <-> t = t0 - loB + i
     zero_acc();
     run_stage(false, stepsA, 0);
+    DMX_STAMP(2);
+    // stage A's channel bias: fetched ONCE, here, for all row fragments.  Inside the tail loop below every iteration paid its own L2
+    // round trip (hipcc puts an s_waitcnt vmcnt(0) in front of each LDS access of a kernel that uses LDS-DMA, so a load issued in one
+    // iteration could not overlap the next): 8-16 serial round trips = 2.6-3.9 us of a 15-25 us workgroup (in-kernel stamps,
+    // scripts/dev/r03_pair_stamps.py)
+    const int fa = P.a.flags;
+    float4 abias[FN];
+#pragma unroll
+    for (int n = 0; n < FN; ++n)
+      abias[n] = (fa & EPI_BIAS) ? *reinterpret_cast<const float4*>(P.a.bias + cg * 64 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (P.r_from_slab) {
       // the residual of stage B is the input of stage A: output row r (t = t0 + r) is slab row r + loA + loB; keep this lane's
       // accumulator-layout pieces in registers before the slab is overwritten by the intermediate
@@ -308,8 +333,8 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
       // everybody must have taken its residual before anybody stores the intermediate
       __syncthreads();
     }
+    DMX_STAMP(6);
     // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
-    const int fa = P.a.flags;
     const float aslope = P.a.act_slope, mslope = P.a.mask_slope;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -325,8 +350,8 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : mslope;
         }
-        if (fa & EPI_BIAS) {
-          const float4 bb = *reinterpret_cast<const float4*>(P.a.bias + ch);
+        {
+          const float4 bb = abias[n];
           v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
         }
         if (fa & EPI_LRELU2) {
@@ -338,26 +363,36 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
       }
     }
     __syncthreads();
+    DMX_STAMP(7);
     if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only
       // backward only needs its SIGN (the leaky-relu' mask): with EPI_BITS2 one byte per 8 channels goes out (a.B2) and the
       // 16-bit tensor itself is written only when a caller still wants it (a.C2 non-null and not bits-only)
       const bool bits = (fa & EPI_BITS2) != 0, full = !P.a_tape_bits_only;
+      // all LDS reads first, then all global stores (interleaved, each read waited for the previous iteration's store to complete:
+      // the same compiler-inserted vmcnt(0) as above)
+      uint4 tv[K::BITS_IT];
+#pragma unroll
+      for (int it = 0; it < K::BITS_IT; ++it) {
+        const int c = tid + it * NT, row = c / CPR, piece = c % CPR;
+        tv[it] = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
+      }
 #pragma unroll
       for (int it = 0; it < K::BITS_IT; ++it) {
         const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
         if (row >= P.loB && row < P.loB + P.BMo && t < T) {
-          const uint4 v = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
-          if (full) *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = v;
-          if (bits) P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)dmx_pos8(v);
+          if (full) *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = tv[it];
+          if (bits) P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)dmx_pos8(tv[it]);
         }
       }
     }
   }
 
   // ---- stage B: output row r <-> t = t0 + r reads intermediate rows r + (tap offset + loB)
+  DMX_STAMP(3);
   zero_acc();
   run_stage(true, stepsB, stepsA);
   __syncthreads();
+  DMX_STAMP(4);
   {
     constexpr int EPI_WAVE_BYTES = 64 * (FN * 32 + 16) + 64 * 12;
     static_assert(EPI_WAVE_BYTES * NW <= K::SLAB_BYTES, "epilogue staging does not fit the slab");
@@ -366,6 +401,11 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
     gemm_epilogue_lds_impl<4, FN, 1>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
                                         !single && P.r_from_slab != 0);
   }
+  DMX_STAMP(5);
+#ifdef DMX_PAIR_STAMPS
+  if (threadIdx.x == 0 && stamp_id < 4096)
+    for (int i = 0; i < 8; ++i) g_pair_stamps[stamp_id * 8 + i] = stamp_v[i];
+#endif
 }
 
 template <int C>
@@ -555,3 +595,9 @@ int dmx_conv_pair_group_launch(int n, const GemmDesc* const* a, const GemmDesc* 
   dmx_prof_close(rec, st, fl, by, b[0]->M, C, Ksum, b[0]->ntaps, b[0]->flags, 22);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
+
+#ifdef DMX_PAIR_STAMPS
+extern "C" int dmx_pair_stamps_read(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pair_stamps), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -230,8 +230,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       }
       }
     };
-    // EPI_BITS2: a separate sweep over the packed tile stage_out left in LDS (kept out of the store loop above: the common
-    // path must not pay for it) -- one byte per 16-byte chunk, bit e <=> channel ncol + e > 0, the backward sweep's leaky-relu' mask
+    // EPI_BITS2: a separate sweep over the packed tile stage_out left in LDS -- one byte per 16-byte chunk, bit e <=> channel ncol + e > 0,
+    // the backward sweep's leaky-relu' mask.  (Taking the bytes from the registers of the store loop instead was measured in round 3:
+    // no gain forward, 5-8 % slower C = 32 backward instances through register allocation; scripts/dev/pair_bench.py.)
     auto emit_bits = [&]() {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -246,19 +247,31 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       const float sl = p.mask_slope;
       const bool span_ok = n0 + FN * 16 <= p.N;
       const int sh0 = 8 * (lq >> 1) + 4 * (lq & 1);             // bit position of this lane's nibble inside a 16-column pair
+      // all IB mask words are fetched before the first one is used: with load and use in one loop body every row fragment paid its own
+      // L2 round trip (in-kernel stamps of the pair kernel, scripts/dev/r03_pair_stamps.py)
+      uint32_t q0s[IB], q1s[IB];
+      int orow_s[IB];
 #pragma unroll
       for (int ii = 0; ii < IB; ++ii) {
         const int r = ii * 16 + lr;
-        int orow;
-        if (ident) { const int m = m0 + h * CH + r; orow = m < mend ? m : -1; }
-        else orow = tab[r];
-        uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu;
-        if (orow >= 0) {
-          const unsigned char* src = p.XB + (long long)orow * p.ldxb + (n0 >> 3);
-          if (span_ok) {
-            if constexpr (FN == 4) { const uint2 q = *reinterpret_cast<const uint2*>(src); q0 = q.x; q1 = q.y; }
-            else q0 = *reinterpret_cast<const uint32_t*>(src);
-          } else {                                              // N tail (narrow layers: N = 8 / 16 inside a 32-column wave tile)
+        if (ident) { const int m = m0 + h * CH + r; orow_s[ii] = m < mend ? m : -1; }
+        else orow_s[ii] = tab[r];
+      }
+      if (span_ok) {                                            // (wave-uniform) straight-line loads from always-valid rows: one round trip for all
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          const unsigned char* src = p.XB + (long long)(orow_s[ii] >= 0 ? orow_s[ii] : 0) * p.ldxb + (n0 >> 3);
+          if constexpr (FN == 4) { const uint2 q = *reinterpret_cast<const uint2*>(src); q0s[ii] = q.x; q1s[ii] = q.y; }
+          else { q0s[ii] = *reinterpret_cast<const uint32_t*>(src); q1s[ii] = 0xffffffffu; }
+        }
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) if (orow_s[ii] < 0) { q0s[ii] = 0xffffffffu; q1s[ii] = 0xffffffffu; }
+      } else {                                                  // N tail (narrow layers: N = 8 / 16 inside a 32-column wave tile)
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          uint32_t q0 = 0xffffffffu, q1 = 0xffffffffu;
+          if (orow_s[ii] >= 0) {
+            const unsigned char* src = p.XB + (long long)orow_s[ii] * p.ldxb + (n0 >> 3);
             q0 = q1 = 0u;
 #pragma unroll 1                 // rare path: keep it rolled (unrolled, its byte loads were hoisted and cost ~50 VGPRs everywhere)
             for (int k = 0; k < FN * 2; ++k) {
@@ -266,7 +279,12 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
               if (k < 4) q0 |= by << (8 * k); else q1 |= by << (8 * (k - 4));
             }
           }
+          q0s[ii] = q0; q1s[ii] = q1;
         }
+      }
+#pragma unroll
+      for (int ii = 0; ii < IB; ++ii) {
+        const uint32_t q0 = q0s[ii], q1 = q1s[ii];
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const unsigned nib = ((j < 2 ? q0 : q1) >> (sh0 + 16 * (j & 1)));
