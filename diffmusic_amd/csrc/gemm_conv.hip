@@ -171,6 +171,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 // range and the hardware range check returns zeros.  Two LDS stages, one barrier per K-step.
 constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors below
 
+#ifdef DMX_GEMM_STAMPS
+// diagnostic build only (scripts/dev/r03_gemm_stamps.py): 100 MHz wall-clock stamps of the phases of the first 8192 workgroups of the
+// last launch: entry | ring prologue landed | K loop done | epilogue done, and the hardware id (XCC / SE / CU) the workgroup ran on
+__device__ unsigned long long g_gemm_stamps[8192 * 5];
+#define DMX_GSTAMP(i) do { gstamp_v[i] = wall_clock64(); } while (0)
+#else
+#define DMX_GSTAMP(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EM>
 __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
   constexpr int NW = WM * WN;
@@ -185,6 +194,10 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef DMX_GEMM_STAMPS
+  unsigned long long gstamp_v[4] = {0, 0, 0, 0};
+#endif
+  DMX_GSTAMP(0);
   const int z = blockIdx.y;
   const int zo = z / p.Zi, zi = z - zo * p.Zi;
   const act_t* Ab = p.A + zo * p.sAo + zi * p.sAi;
@@ -322,6 +335,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
+  DMX_GSTAMP(1);
 
   // Hand-scheduled fragment pipeline.  hipcc sinks every ds_read next to its consumer (read 2, wait, 4-8 MFMAs: the LDS
   // latency is exposed 16x per K-step and the matrix pipe idles ~50 %).  Here the reads are inline asm issued two steps
@@ -459,6 +473,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
 #undef DMX_DSR
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill tail ...
   __builtin_amdgcn_s_barrier();                          // ... of every wave before the stage buffers are reused by the epilogue
+  DMX_GSTAMP(2);
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
@@ -467,6 +482,21 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
     gemm_epilogue_lds<FM, FN, EM>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
+#ifdef DMX_GEMM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores of the epilogue have left the wave
+  DMX_GSTAMP(3);
+  {
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (tid == NW * 64 - 64 && wg < 8192) {              // lane 0 of the LAST wave (the lagging half: it leaves the K loop last)
+      unsigned hw, xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g_gemm_stamps[wg * 5 + i] = gstamp_v[i];
+      g_gemm_stamps[wg * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+    }
+  }
+#endif
 }
 
 // XCD-aware remap (blocks are dealt round-robin over the 8 XCDs): give each XCD a contiguous run of logical tiles so the
@@ -665,6 +695,12 @@ extern "C" void dmx_prof_begin(void) {
 // stops recording; returns the number of launches, total kernel milliseconds and algorithmic FLOPs (2*M*N*K*Z)
 static double g_dma_ms = 0.0, g_dma_fl = 0.0, g_dma_by = 0.0;
 static int g_dma_n = 0;
+#ifdef DMX_GEMM_STAMPS
+extern "C" int dmx_gemm_stamps_read(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 8192 * 5) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // share of the last profiled region that ran in gemm_glds_kernel (the dominant, MFMA-bound kernel)
 extern "C" int dmx_prof_dominant(double* ms, double* flops, double* bytes) {
   if (ms) *ms = g_dma_ms;
