@@ -38,16 +38,16 @@ __global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __re
   float s1[8], s2[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.f;
-  float sc[8], sf[8], mu[8], rs[8];
+  // (backward sums: s2 accumulates dxhat * (x - mean); the group's rstd is a common factor and is applied once at the end -- eight
+  //  registers and one multiply per element less inside the loop, which is what lets it keep two rows in flight)
+  float sc[8], sf[8], mu[8];
   if (MODE == 1) {
     const int cpg = C / G;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       sc[i] = scale[(long long)b * C + c0 + i];
       sf[i] = shift[(long long)b * C + c0 + i];
-      const int g = (c0 + i) / cpg;
-      mu[i] = stats[((long long)b * G + g) * 2];
-      rs[i] = stats[((long long)b * G + g) * 2 + 1];
+      mu[i] = stats[((long long)b * G + (c0 + i) / cpg) * 2];
     }
   }
   const act_t* xb = x + (long long)b * P * C;
@@ -66,14 +66,13 @@ __global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __re
         const float z = f[i] * sc[i] + sf[i];
         const float dz = silu ? d[i] * dsilu_f(z) : d[i];
         const float dxh = dz * sc[i];              // = dz*gamma*rstd ; divide rstd out in finalize
-        const float xh = (f[i] - mu[i]) * rs[i];
-        s1[i] += dxh; s2[i] += dxh * xh;
+        s1[i] += dxh; s2[i] += dxh * (f[i] - mu[i]);
       }
     }
   };
   int p = p0 + row;
   for (; MODE == 0 && p + 3 * rpb < p1; p += 4 * rpb) {   // stats pass: four independent 16-B loads in flight per thread
-    // (the backward sums keep the plain loop: unrolling them costs registers/occupancy and measured 2x slower)
+    // (the backward sums unrolled FOUR rows deep measured 2x slower: registers / occupancy; they take the two-row loop below)
     uint4 xv[4], dv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -83,10 +82,25 @@ __global__ void gn_partial_kernel(const act_t* __restrict__ x, const act_t* __re
 #pragma unroll
     for (int u = 0; u < 4; ++u) body(xv[u], dv[u]);
   }
+  for (; MODE == 1 && p + rpb < p1; p += 2 * rpb) {       // backward sums: two rows x two tensors = four 16-B loads in flight per thread
+    uint4 xv[2], dv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      xv[u] = *reinterpret_cast<const uint4*>(xb + (long long)(p + u * rpb) * C + c0);
+      dv[u] = *reinterpret_cast<const uint4*>(db + (long long)(p + u * rpb) * C + c0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) body(xv[u], dv[u]);
+  }
   for (; p < p1; p += rpb) {
     uint4 dv = make_uint4(0, 0, 0, 0);
     if (MODE == 1) dv = *reinterpret_cast<const uint4*>(db + (long long)p * C + c0);
     body(*reinterpret_cast<const uint4*>(xb + (long long)p * C + c0), dv);
+  }
+  if (MODE == 1) {
+    const int cpg = C / G;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s2[i] *= stats[((long long)b * G + (c0 + i) / cpg) * 2 + 1];
   }
   float* my = sh + ((long long)row * C + c0) * 2;
 #pragma unroll

@@ -234,6 +234,8 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       r_iy[i] = -(1 << 20); r_ix[i] = 0;
       if (m < p.M) {
         int b = 0, qy = 0, qx = m;                                   // plain GEMM rows (one "image" of M x 1 pixels): no divisions
+        // (hoisting the divisions out -- image / pixel of the tile's first row once, rows by offset -- leaves the 3.3-6 us a workgroup
+        //  spends before its first MFMA unchanged: that time is the latency of the ring's first loads; scripts/dev/r03_gemm_stamps.py)
         if (!(p.Hq == 1 && p.Wq >= p.M)) {
           b = m / HqWq; const int rem = m - b * HqWq;
           qy = rem / p.Wq; qx = rem - qy * p.Wq;
