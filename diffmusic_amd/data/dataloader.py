@@ -16,26 +16,31 @@ from torch.utils.data import DataLoader, Dataset
 
 from ..pipelines.prompt_audioldm2 import resample_to
 
-__DATASET__ = {}
+_REGISTRY = {}                    # dataset type ("wav") -> class
 
 
 def register_dataset(name):
-    def wrapper(cls):
-        if __DATASET__.get(name, None):
-            raise NameError(f"Name {name} is already registered!")
-        __DATASET__[name] = cls
+    """Class decorator: make `cls` available to `get_dataset(type=name)`; a type can be registered once."""
+    def bind(cls):
+        if name in _REGISTRY:
+            raise NameError(f"dataset type {name!r} is already registered ({_REGISTRY[name].__name__})")
+        _REGISTRY[name] = cls
         return cls
-    return wrapper
+    return bind
 
 
 def get_dataset(name, type, root, **kwargs):
-    if __DATASET__.get(type, None) is None:
-        raise NameError(f"Dataset {type} is not defined.")
-    return __DATASET__[type](root=root, **kwargs)
+    """`name` is the corpus label of the reference's configs (unused by the loader itself), `type` selects the registered class."""
+    try:
+        cls = _REGISTRY[type]
+    except KeyError:
+        raise NameError(f"dataset type {type!r} is not registered (known: {sorted(_REGISTRY)})") from None
+    return cls(root=root, **kwargs)
 
 
 def get_dataloader(dataset, batch_size, num_workers, train):
-    return DataLoader(dataset, batch_size, shuffle=train, num_workers=num_workers, drop_last=train)
+    # evaluation keeps file order and the ragged last batch; training shuffles and drops it
+    return DataLoader(dataset, batch_size=batch_size, num_workers=num_workers, shuffle=bool(train), drop_last=bool(train))
 
 
 def load_wav(path):
@@ -70,25 +75,32 @@ def load_wav(path):
 
 
 @register_dataset(name="wav")
-class WAVDataset(Dataset):                                  # dataloader.py:47-89
+class WAVDataset(Dataset):
+    """All `*.wav` files below `root` (sorted), each as (mono waveform cropped to [start_s, end_s) at `sample_rate`, file name).
+    Reference: diffmusic/data/dataloader.py:47-89."""
+
     def __init__(self, root, sample_rate, audio_length_in_s, start_s=0, end_s=0, transforms=None):
-        self.root, self.sample_rate, self.audio_length_in_s = root, sample_rate, audio_length_in_s
-        self.start_s, self.end_s, self.transforms = start_s, end_s, transforms
-        self.fpaths = sorted(glob(root + "/**/*.wav", recursive=True))
-        assert len(self.fpaths) > 0, "File list is empty. Check the root."
+        self.root = root
+        self.sample_rate = sample_rate
+        self.audio_length_in_s = audio_length_in_s
+        self.start_s, self.end_s = start_s, end_s
+        self.transforms = transforms
+        self.fpaths = sorted(glob(os.path.join(root, "**", "*.wav"), recursive=True))
+        if not self.fpaths:
+            raise AssertionError(f"no .wav files below {root!r}")
 
     def __len__(self):
         return len(self.fpaths)
 
+    def _crop(self):
+        return slice(int(self.start_s * self.sample_rate), int(self.end_s * self.sample_rate))
+
     def __getitem__(self, index):
-        fpath = self.fpaths[index]
-        wave, sr = load_wav(fpath)                          # (channels, time)
-        if wave.size(0) > 1:
-            wave = wave.mean(dim=0, keepdim=True)
-        if sr != self.sample_rate:
-            wave = resample_to(wave, sr, self.sample_rate)
+        path = self.fpaths[index]
+        audio, rate = load_wav(path)                        # (channels, time)
+        mono = audio if audio.shape[0] == 1 else audio.mean(dim=0, keepdim=True)
+        if rate != self.sample_rate:
+            mono = resample_to(mono, rate, self.sample_rate)
         if self.transforms is not None:
-            wave = self.transforms(wave)
-        wave = wave[0]
-        gt_wave = wave[int(self.start_s * self.sample_rate): int(self.end_s * self.sample_rate)]
-        return gt_wave, os.path.basename(fpath)
+            mono = self.transforms(mono)
+        return mono[0][self._crop()], os.path.basename(path)
