@@ -24,7 +24,7 @@ if [ $part = all ] || [ $part = prof ]; then
   DMX_PROF_CSV=$out/${tag}_gemm_shapes.csv timeout -k 10 200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-stage-times > /dev/null 2>&1
   rm -rf /tmp/pu; timeout -k 10 200 rocprofv3 --kernel-trace --stats -d /tmp/pu -o u --output-format csv -- python scripts/dev/unet_only.py > $out/unet_run.log 2>&1 || tail -3 $out/unet_run.log
   cp $(find /tmp/pu -name "*kernel_stats.csv" | head -1) $out/${tag}_unet_only_kernel_stats.csv
-  for wl in dsg_phase_audioldm2 diffmusic_style_audioldm2; do
+  for wl in dsg_phase_audioldm2 mpgd_sr4 diffmusic_style_audioldm2; do
     rm -rf /tmp/pw; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d /tmp/pw -o w --output-format csv -- python bench.py --workload $wl --steps 4 --warmup 1 --no-cpu-baseline --no-stage-times > $out/prof_$wl.log 2>&1 || tail -3 $out/prof_$wl.log
     cp $(find /tmp/pw -name "*kernel_stats.csv" | head -1) $out/${tag}_bench_${wl}_kernel_stats.csv
   done
