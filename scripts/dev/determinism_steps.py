@@ -7,7 +7,7 @@ for wl in ("dps_inpainting", "dsg_phase_audioldm2", "mpgd_sr4"):
     outs = []
     for rep in range(2):
         torch.manual_seed(0)
-        pipe, op, meas, lat, cond, L = bench.build_problem(2, 0, dev, wl)
+        pipe, op, meas, lat, cond, L = bench.build_problem(int(sys.argv[1]) if len(sys.argv) > 1 else 2, 0, dev, wl)
         ts = pipe.scheduler._timesteps_host
         for k in range(3):
             lat, loss = bench.one_step(pipe, lat, ts[k], cond, meas, L)
