@@ -173,8 +173,9 @@ constexpr unsigned OOB = 0x80000000u;   // == num_records of the descriptors bel
 
 #ifdef DMX_GEMM_STAMPS
 // diagnostic build only (scripts/dev/r03_gemm_stamps.py): 100 MHz wall-clock stamps of the phases of the first 8192 workgroups of the
-// last launch: entry | ring prologue landed | K loop done | epilogue done, and the hardware id (XCC / SE / CU) the workgroup ran on
-__device__ unsigned long long g_gemm_stamps[8192 * 5];
+// last launch: entry | ring prologue landed | K loop done | epilogue's last store issued | stores acknowledged, and the hardware id
+// (XCC / SE / CU) the workgroup ran on
+__device__ unsigned long long g_gemm_stamps[8192 * 6];
 #define DMX_GSTAMP(i) do { gstamp_v[i] = wall_clock64(); } while (0)
 #else
 #define DMX_GSTAMP(i) do { } while (0)
@@ -195,7 +196,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef DMX_GEMM_STAMPS
-  unsigned long long gstamp_v[4] = {0, 0, 0, 0};
+  unsigned long long gstamp_v[5] = {0, 0, 0, 0, 0};
 #endif
   DMX_GSTAMP(0);
   const int z = blockIdx.y;
@@ -485,8 +486,9 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     gemm_epilogue_lds<FM, FN, EM>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
   }
 #ifdef DMX_GEMM_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the stores of the epilogue have left the wave
-  DMX_GSTAMP(3);
+  DMX_GSTAMP(3);                                         // every store of the epilogue issued ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ... and acknowledged
+  DMX_GSTAMP(4);
   {
     const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
     if (tid == NW * 64 - 64 && wg < 8192) {              // lane 0 of the LAST wave (the lagging half: it leaves the K loop last)
@@ -494,8 +496,8 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g_gemm_stamps[wg * 5 + i] = gstamp_v[i];
-      g_gemm_stamps[wg * 5 + 4] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
+      for (int i = 0; i < 5; ++i) g_gemm_stamps[wg * 6 + i] = gstamp_v[i];
+      g_gemm_stamps[wg * 6 + 5] = ((unsigned long long)(xcc & 0xf) << 32) | hw;
     }
   }
 #endif
@@ -699,7 +701,7 @@ static double g_dma_ms = 0.0, g_dma_fl = 0.0, g_dma_by = 0.0;
 static int g_dma_n = 0;
 #ifdef DMX_GEMM_STAMPS
 extern "C" int dmx_gemm_stamps_read(unsigned long long* host) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 8192 * 5) == hipSuccess ? 0 : -1;
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_stamps), sizeof(unsigned long long) * 8192 * 6) == hipSuccess ? 0 : -1;
 }
 #endif
 
