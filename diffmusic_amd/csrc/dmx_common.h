@@ -31,7 +31,19 @@ typedef __attribute__((ext_vector_type(8))) _Float16 frag8_t;
 
 __device__ __forceinline__ float a2f(act_t v) { return (float)__builtin_bit_cast(native16_t, v); }
 __device__ __forceinline__ act_t f2a(float f) { return __builtin_bit_cast(act_t, (native16_t)f); }
+// two floats -> one packed pair of 16-bit activations (round to nearest even).  Written as a 2-vector conversion so that it becomes ONE
+// v_cvt_pk_f16_f32: as (f2a(lo) | f2a(hi) << 16) a 4-element pack was compiled into conversions of the (0, 2) and (1, 3) pairs plus four
+// and / shift / or instructions to re-interleave them (GEMM epilogue staging loop: -0.3 ... -0.7 us per 320 x 256 tile, in-kernel stamps)
+#ifdef DMX_BF16
 __device__ __forceinline__ uint32_t pack2a(float lo, float hi) { return (uint32_t)f2a(lo) | ((uint32_t)f2a(hi) << 16); }
+#else
+__device__ __forceinline__ uint32_t pack2a(float lo, float hi) {
+  typedef float dmx_f32x2 __attribute__((ext_vector_type(2)));
+  typedef _Float16 dmx_f16x2 __attribute__((ext_vector_type(2)));
+  const dmx_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dmx_f16x2));
+}
+#endif
 __device__ __forceinline__ float alo(uint32_t u) { return a2f((act_t)(u & 0xffffu)); }
 __device__ __forceinline__ float ahi(uint32_t u) { return a2f((act_t)(u >> 16)); }
 

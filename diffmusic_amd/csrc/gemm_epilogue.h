@@ -204,14 +204,14 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     auto stage_out = [&](act_t* G, int ld, auto&& f) {
       // (GEGLU: only the even fragments carry results; they are packed into the left half of the tile rows and leave as N / 2 columns)
       constexpr int JS = GEGLU ? 2 : 1;
-#pragma unroll
-      for (int ii = 0; ii < IB; ++ii)
-#pragma unroll
-        for (int j = 0; j < FN; j += JS) {
+      static_for<0, IB>([&](auto II) {
+        static_for<0, FN / JS>([&](auto JJ) {
+          constexpr int ii = decltype(II)::value, j = decltype(JJ)::value * JS;
           float o[4];
           f(acc[h * IB + ii][j], o);
           *reinterpret_cast<uint2*>(wl + (ii * 16 + lr) * PITCH + ((j / JS) * 16 + lq * 4) * 2) = make_uint2(pack2a(o[0], o[1]), pack2a(o[2], o[3]));
-        }
+        });
+      });
       DMX_LDS_SYNC();
       constexpr int HN = NIT > 4 ? NIT / 2 : NIT;      // row-major read / store in groups of <= 4 instructions (register pressure)
 #pragma unroll
