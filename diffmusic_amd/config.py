@@ -2,7 +2,12 @@
 image): `compose("dps", overrides=["data=moises", "model=musicldm"])` reads configs/<name>.yaml, then
 resolves its `defaults:` list into sub-trees configs/<group>/<choice>.yaml (reference: run.py:147-151)."""
 import os
+import re
 import yaml
+
+# OmegaConf (what the reference's hydra loads these files with) reads `5e-5` as a float; PyYAML's YAML-1.1 resolver wants a dot in the
+# mantissa and returns the string.  Same values as the reference sees: exponent-form strings become floats.
+_EXP_FLOAT = re.compile(r"^[-+]?(\d+\.?\d*|\.\d+)[eE][-+]?\d+$")
 
 CONFIG_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs")
 
@@ -16,6 +21,8 @@ class Node(dict):
             return Node({k: Node.wrap(v) for k, v in x.items()})
         if isinstance(x, list):
             return [Node.wrap(v) for v in x]
+        if isinstance(x, str) and _EXP_FLOAT.match(x):
+            return float(x)
         return x
 
 

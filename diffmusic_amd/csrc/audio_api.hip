@@ -45,14 +45,12 @@ static bool build_fused_tables(dmx_audio* a, const float* fb) {
                o_mlo = place(NBP * 4), o_mlen = place(NBP * 4), o_fbc = place(fbc.size() * 4), o_fbr = place(fbr.size() * 4);
   char* d = nullptr;
   if (hipMalloc(&d, off) != hipSuccess) return false;
-  hipMemcpy(d + o_tw, tw.data(), tw.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_win, win.data(), win.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_klo, klo.data(), NMv * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_klen, klen.data(), NMv * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_mlo, mlo.data(), NBP * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_mlen, mlen.data(), NBP * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_fbc, fbc.data(), fbc.size() * 4, hipMemcpyHostToDevice);
-  hipMemcpy(d + o_fbr, fbr.data(), fbr.size() * 4, hipMemcpyHostToDevice);
+  // every table upload is checked: a failed copy returns false and the dense-DFT path is used (a half-filled table must never be read)
+  const struct { size_t off; const void* src; size_t bytes; } ups[] = {
+      {o_tw, tw.data(), tw.size() * 4}, {o_win, win.data(), win.size() * 4}, {o_klo, klo.data(), (size_t)NMv * 4}, {o_klen, klen.data(), (size_t)NMv * 4},
+      {o_mlo, mlo.data(), (size_t)NBP * 4}, {o_mlen, mlen.data(), (size_t)NBP * 4}, {o_fbc, fbc.data(), fbc.size() * 4}, {o_fbr, fbr.data(), fbr.size() * 4}};
+  for (const auto& u : ups)
+    if (hipMemcpy(d + u.off, u.src, u.bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return false; }
   a->fused_mem = d;
   a->ft.tw = (const float2*)(d + o_tw); a->ft.win = (const float*)(d + o_win);
   a->ft.klo = (const int*)(d + o_klo); a->ft.klen = (const int*)(d + o_klen); a->ft.fbc = (const float*)(d + o_fbc); a->ft.kmax = kmax;

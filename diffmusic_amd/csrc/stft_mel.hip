@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void stft_mel_bwd_kernel(const SmParams P) {
   __shared__ float s_dv[4][NM];
   __shared__ float s_acc[4][BWD_MAX_CHUNK];
   __shared__ float s_inv;
+  // ~71.7 KB of static LDS: legal because gfx950 has 160 KiB per CU (other gfx9 parts stop at 64 KiB); two workgroups share a CU
+  static_assert(sizeof(float2) * NF * 5 + sizeof(float) * (4 * NBP + 4 * NM + 4 * BWD_MAX_CHUNK + 1) <= 80 * 1024,
+                "stft_mel_bwd_kernel: two workgroups per CU must fit the 160 KiB of gfx950 LDS");
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "stft_mel.hip sizes its LDS for gfx950 (160 KiB per CU)"
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const int L = P.L, hop = P.hop;

@@ -268,7 +268,21 @@ at::Tensor hifigan_bwd(int64_t model, const at::Tensor& dwav, int64_t frames, in
 
 }  // namespace
 
+// the version of include/diffmusic_hip.h this op library was COMPILED against (the loaded libdiffmusic_hip.so reports its own through
+// dmx_abi_version(); the two are compared when the library is loaded, below)
+int64_t abi_version() { return DMX_ABI_VERSION; }
+
 TORCH_LIBRARY(diffmusic_hip, m) {
+  // A stale or copied op library would call entry points of another ABI version with this one's struct layouts and argument lists
+  // (version 2 changed dmx_flash_attn_raw and GemmDesc): refuse to load instead -- torch.ops.load_library raises, and
+  // diffmusic_amd.ops.enabled() falls back to the ctypes binding (which checks the same number) with one warning.
+  TORCH_CHECK(dmx_abi_version() == DMX_ABI_VERSION, "libdiffmusic_torch_ops.so was built against C-ABI version ", DMX_ABI_VERSION,
+              " but the loaded libdiffmusic_hip.so reports ", dmx_abi_version(), ": rebuild with `python -m diffmusic_amd.build`");
+  m.def("abi_version() -> int", &abi_version);
+  // Schemas: ops that write into a caller-owned tensor besides their outputs declare it (a!): `state` of the measurement front end
+  // (written by *_fwd / mel_guidance, read by the matching *_bwd) and the network workspaces `ws` (written by *_fwd; the model handle's
+  // tape points into it and *_bwd reads it).  Handles travel as ints: effects behind a handle are invisible to the schema, so under
+  // torch.compile / functionalization a forward and its backward must still be kept in program order by the caller (eager use today).
   m.def("sched_pred_x0(Tensor x, Tensor eps, float alpha_t) -> Tensor", &sched_pred_x0);
   m.def("cfg_combine(Tensor eps2, float scale) -> Tensor", &cfg_combine);
   m.def("sched_update(int mode, Tensor x, Tensor eps, Tensor x0, Tensor? g0, Tensor? inv_scale, Tensor? noise, float alpha_t, float alpha_prev, "
@@ -278,18 +292,18 @@ TORCH_LIBRARY(diffmusic_hip, m) {
   m.def("l2norm(Tensor ref, Tensor pred, float gscale) -> (Tensor, Tensor)", &l2norm);
   m.def("resample_fwd(Tensor x, Tensor h, int Lin, int Lout, int orig, int new_, int off) -> Tensor", &resample_fwd);
   m.def("resample_bwd(Tensor dy, Tensor h, Tensor? h_rev, int Lin, int Lfull, int orig, int new_, int off) -> Tensor", &resample_bwd);
-  m.def("logmel_fwd(int audio, Tensor wav, Tensor state, int L, bool power2, bool to_db, float lo, float hi) -> Tensor", &logmel_fwd);
+  m.def("logmel_fwd(int audio, Tensor wav, Tensor(a!) state, int L, bool power2, bool to_db, float lo, float hi) -> Tensor", &logmel_fwd);
   m.def("logmel_bwd(int audio, Tensor dmel, Tensor state, int L, bool power2, bool to_db, float lo, float hi) -> Tensor", &logmel_bwd);
-  m.def("mel_guidance(int audio, Tensor wav, Tensor? mask, Tensor ref, Tensor state, int L, int Lfull, bool power2, bool to_db, float lo, float hi, "
+  m.def("mel_guidance(int audio, Tensor wav, Tensor? mask, Tensor ref, Tensor(a!) state, int L, int Lfull, bool power2, bool to_db, float lo, float hi, "
         "float gscale) -> (Tensor, Tensor)", &mel_guidance);
-  m.def("stft_mag_fwd(int audio, Tensor wav, Tensor state, int L) -> Tensor", &stft_mag_fwd);
+  m.def("stft_mag_fwd(int audio, Tensor wav, Tensor(a!) state, int L) -> Tensor", &stft_mag_fwd);
   m.def("stft_mag_bwd(int audio, Tensor dmag, Tensor state, int L, int Lfull) -> Tensor", &stft_mag_bwd);
   m.def("melscale_fwd(int audio, Tensor mag, float lo, float hi) -> Tensor", &melscale_fwd);
-  m.def("unet_fwd(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor ws) -> Tensor", &unet_fwd);
-  m.def("unet_fwd_ctx(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor c0, Tensor c1, Tensor bias1, Tensor ws) -> Tensor", &unet_fwd_ctx);
-  m.def("vae_dec_fwd(int model, Tensor z, float z_scale, bool keep_state, bool want_f32, int scale_factor, Tensor ws) -> (Tensor, Tensor?)", &vae_dec_fwd);
+  m.def("unet_fwd(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor(a!) ws) -> Tensor", &unet_fwd);
+  m.def("unet_fwd_ctx(int model, Tensor x, Tensor t, Tensor? class_labels, Tensor c0, Tensor c1, Tensor bias1, Tensor(a!) ws) -> Tensor", &unet_fwd_ctx);
+  m.def("vae_dec_fwd(int model, Tensor z, float z_scale, bool keep_state, bool want_f32, int scale_factor, Tensor(a!) ws) -> (Tensor, Tensor?)", &vae_dec_fwd);
   m.def("vae_dec_bwd(int model, Tensor dmel, float z_scale, int latent_channels, int scale_factor) -> Tensor", &vae_dec_bwd);
   m.def("grad_normalize_(Tensor(a!) dwav, float target) -> Tensor", &grad_normalize_);
-  m.def("hifigan_fwd(int model, Tensor mel, Tensor ws) -> Tensor", &hifigan_fwd);
+  m.def("hifigan_fwd(int model, Tensor mel, Tensor(a!) ws) -> Tensor", &hifigan_fwd);
   m.def("hifigan_bwd(int model, Tensor dwav, int frames, int model_in_dim) -> Tensor", &hifigan_bwd);
 }

@@ -23,7 +23,7 @@ _loaded = False
 
 OP_NAMES = ("sched_pred_x0", "cfg_combine", "sched_update", "randn_philox", "mask_mul", "l2norm", "resample_fwd", "resample_bwd",
             "logmel_fwd", "logmel_bwd", "stft_mag_fwd", "stft_mag_bwd", "melscale_fwd", "unet_fwd", "unet_fwd_ctx", "vae_dec_fwd",
-            "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "grad_normalize_", "mel_guidance")
+            "vae_dec_bwd", "hifigan_fwd", "hifigan_bwd", "grad_normalize_", "mel_guidance", "abi_version")
 _usable = None
 
 
@@ -35,7 +35,10 @@ def load():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m diffmusic_amd.build` (no CPU fallback)")
         from . import _lib
         _lib.lib()                                   # libdiffmusic_hip.so first (the op library links it by rpath $ORIGIN)
-        torch.ops.load_library(LIB_PATH)
+        torch.ops.load_library(LIB_PATH)             # (its TORCH_LIBRARY init refuses a libdiffmusic_hip.so of another C-ABI version)
+        if int(torch.ops.diffmusic_hip.abi_version()) != _lib.ABI_VERSION:
+            raise RuntimeError(f"libdiffmusic_torch_ops.so was compiled against C-ABI version {int(torch.ops.diffmusic_hip.abi_version())}, "
+                               f"this package expects {_lib.ABI_VERSION}: rebuild it with `python -m diffmusic_amd.build`")
         _loaded = True
     return torch.ops.diffmusic_hip
 

@@ -19,6 +19,10 @@ CASES = [("ddim", "music_inpainting", 0.0, 0.0, 50, "mel_spectrogram"),
          ("dsg", "music_inpainting", 1.0, 0.08, 200, "mel_spectrogram"),
          ("dsg", "phase_retrieval", 1.0, 0.08, 200, "mel_spectrogram"),
          ("diffmusic", "music_inpainting", 1.0, 0.08, 200, "mel_spectrogram"),
-         ("diffmusic", "music_inpainting", 1.0, 0.9999, 200, "mel_spectrogram")]
+         ("diffmusic", "music_inpainting", 1.0, 0.9999, 200, "mel_spectrogram"),
+         # eta > 0 on the deterministic samplers: the parent DDIM step consumes one draw of the generator before the scheduler's own
+         # variance noise (scheduling_dps.py:166-193, scheduling_mpgd.py:164-173,206-217).  Appended: earlier cases keep their seeds.
+         ("dps", "music_inpainting", 0.5, 5e-4, 200, "mel_spectrogram"),
+         ("mpgd", "music_inpainting", 0.5, 5e-3, 200, "mel_spectrogram")]
 
 

@@ -104,9 +104,9 @@ def test_batched_nt_gemm_f32_out_and_mask():
     assert _rel(outb, ref) < 6e-3
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19])
 def test_forced_tile_configs_agree(cfg):
-    """every tile configuration (incl. the 320x256 LDS-DMA tile) gives the same conv result"""
+    """every tile configuration (incl. the 320x256 and 512x128 LDS-DMA tiles and the register-staged 128x32 tile) gives the same conv result"""
     from diffmusic_amd import _lib as L
     g = torch.Generator().manual_seed(3)
     B, T, Ci, Co, k, dil = 2, 2400, 128, 256, 7, 3

@@ -65,6 +65,12 @@ def test_sched_step_kernel_matches_reference_golden(golden_dir, ci):
         noise = None
         if name in ("dsg", "diffmusic"):
             noise = torch.randn(x.shape, generator=torch.Generator().manual_seed(int(seed)))
+        elif name in ("dps", "mpgd") and eta > 0:
+            # eta > 0: the parent DDIM step takes the generator's FIRST draw (and throws its prev_sample away); the scheduler's own
+            # variance noise is the SECOND (scheduling_dps.py:166-193, scheduling_mpgd.py:164-173,206-217)
+            gen = torch.Generator().manual_seed(int(seed))
+            torch.randn(x.shape, generator=gen)
+            noise = torch.randn(x.shape, generator=gen)
         xd, ed = x.cuda().contiguous(), eps.cuda().contiguous()
         x0d, prev = torch.empty_like(xd), torch.empty_like(xd)
         x0o = torch.empty_like(xd) if name == "mpgd" else None
@@ -80,6 +86,72 @@ def test_sched_step_kernel_matches_reference_golden(golden_dir, ci):
         ref0 = steps[key + "/pred_original_sample"]
         got0 = (x0o if x0o is not None else x0d).cpu().numpy()
         assert np.abs(got0 - ref0).max() <= 5e-5 * max(1.0, np.abs(ref0).max()), key
+
+
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(CASES) if c[0] in ("dps", "mpgd") and c[2] > 0])
+def test_eta_double_draw_through_product_step(golden_dir, ci, monkeypatch):
+    """DPS / MPGD at eta > 0 through the PRODUCT's `Scheduler.step` (host RNG handling + HIP update kernel): with `generator=` the
+    product must throw one draw away (`passes_eta_to_parent`, the parent DDIM step's, scheduling_dps.py:166-175) and use the second as
+    variance noise, or it does not land on the reference's `prev_sample`.  The guidance sweep is replaced by the fixtures' toy decoder
+    chain (autograd), so everything else in `step` is the shipped code."""
+    from diffmusic_amd.schedulers import get_scheduler
+    steps = np.load(os.path.join(golden_dir, "scheduler_steps.npz"))
+    name, task, eta, rate, n_steps, space = CASES[ci]
+    op, vae, voc = _oracle_op(task), ToyVae(), ToyVocoder()
+    sched = get_scheduler(name)(operator=None, **SCHED_CFG)
+    assert sched.passes_eta_to_parent
+    sched.set_timesteps(n_steps)
+    keys = sorted({k.rsplit("/", 1)[0] for k in steps.files if k.startswith(f"c{ci}_")})
+    assert len(keys) == 3
+    for key in keys:
+        t, n, eta_, rate_, seed = steps[key + "/meta"]
+        x, eps, y = (torch.from_numpy(steps[key + "/" + s]) for s in ("x", "eps", "y"))
+
+        def toy_guidance(x0, measurement, vae_, vocoder_, length, supervised_space, op_kwargs=None):
+            x0r = x0.detach().cpu().requires_grad_(True)
+            wav = op.forward(op.inverse_transform(vae.decode(x0r / vae.config.scaling_factor).sample, voc)[:, :L])
+            diff = (y - wav) if supervised_space == "wav_form" else (op.transform(y) - op.transform(wav))
+            loss = torch.linalg.norm(diff)
+            g0 = torch.autograd.grad(loss, x0r)[0]
+            return loss.detach().reshape(1).cuda(), g0.cuda().contiguous(), torch.ones(x0.shape[0], device="cuda")
+
+        monkeypatch.setattr(sched, "_guidance", toy_guidance)
+        o = sched.step(eps.cuda(), int(t), x.cuda(), eta=eta, generator=torch.Generator().manual_seed(int(seed)), measurement=y,
+                       vae=vae, vocoder=voc, original_waveform_length=L, ip_guidance_rate=rate, supervised_space=space)
+        torch.cuda.synchronize()
+        for f in ("prev_sample", "pred_original_sample"):
+            ref, got = steps[key + "/" + f], getattr(o, f).cpu().numpy()
+            assert np.abs(got - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), (key, f, float(np.abs(got - ref).max()))
+        assert abs(float(o.loss) - float(steps[key + "/loss"].reshape(-1)[0])) <= 1e-4 * max(1.0, float(steps[key + "/loss"].reshape(-1)[0]))
+        # a single draw (what a scheduler that ignores the parent's draw would use) does NOT reproduce the reference
+        one = torch.randn(x.shape, generator=torch.Generator().manual_seed(int(seed)))
+        o1 = sched.step(eps.cuda(), int(t), x.cuda(), eta=eta, variance_noise=one.cuda(), measurement=y, vae=vae, vocoder=voc,
+                        original_waveform_length=L, ip_guidance_rate=rate, supervised_space=space)
+        assert np.abs(o1.prev_sample.cpu().numpy() - steps[key + "/prev_sample"]).max() > 1e-3
+
+
+def test_operator_fixtures_one_hop_hip(golden_dir):
+    """The reference-generated operator fixtures fed straight to the HIP operators (one hop HIP == reference): rectangular-window
+    |STFT| of `PhaseRetrievalOperator.forward` (operator.py:162-171) and the reverb convolution of
+    `MusicDereverberationOperator.forward` with the fixture's impulse response (operator.py:238-250)."""
+    from diffmusic_amd import inverse_problem as P
+    fx = np.load(os.path.join(golden_dir, "operators.npz"))
+    wav = torch.from_numpy(fx["wav"]).cuda()
+    mag = P.PhaseRetrievalOperator(noiser=None).forward(wav)
+    ref = fx["phase_retrieval/forward"]
+    assert tuple(mag.shape) == ref.shape == (2, 513, 26)
+    err = float(np.abs(mag.cpu().numpy() - ref).max())
+    assert err <= 2e-4 * max(1.0, float(np.abs(ref).max())), err
+    dr = P.MusicDereverberationOperator(ir_length=500, decay_factor=0.99, noiser=None)
+    out = dr.forward(wav, ir=torch.from_numpy(fx["dereverb_seed77/ir"]))
+    ref = fx["dereverb_seed77/forward"]
+    assert tuple(out.shape) == ref.shape == (2, 4001)
+    err = float(np.abs(out.cpu().numpy() - ref).max())
+    assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), err
+    # the product draws its own response like the reference does (global RNG, operator.py:244-246): same seed, same response
+    torch.manual_seed(77)
+    out2 = dr.forward(wav)
+    assert float(np.abs(out2.cpu().numpy() - ref).max()) <= 1e-4 * max(1.0, float(np.abs(ref).max()))
 
 
 @pytest.mark.parametrize("length", [160000, 6400])

@@ -64,6 +64,22 @@ def test_config_composition_reads_reference_keys():
     assert compose("ddim", overrides=["model=audioldm2", "scheduler.eta=0.5"]).scheduler.eta == 0.5
 
 
+def test_configs_match_reference_values():
+    """The YAMLs are the reference's own (north_star: same config files).  Pins the values that once drifted from
+    /root/reference/configs/data/music_data.yaml:1-13 and /root/reference/configs/diffmusic.yaml:13, and that every dataset type a
+    shipped data config names is one the loader registers."""
+    from diffmusic_amd.config import compose
+    from diffmusic_amd.data import dataloader as D
+    c = compose("diffmusic", overrides=["data=music_data"])
+    assert (c.data.name, c.data.type, c.data.root) == ("musiccaps", "wav", "./data/musiccaps_subset")
+    assert (c.data.start_s, c.data.end_s, c.data.start_inpainting_s, c.data.end_inpainting_s) == (0, 5, 2, 3)
+    assert c.scheduler.optim_prompt_learning_rate == 5e-5 and c.scheduler.ip_guidance_rate == 0.08 and c.scheduler.eta == 1.0
+    m = compose("dps", overrides=["data=moises"]).data
+    assert (m.start_s, m.end_s, m.start_inpainting_s, m.end_inpainting_s) == (10, 15, 12, 13)
+    for choice in ("moises", "music_data"):
+        assert compose("dps", overrides=[f"data={choice}"]).data.type in D._REGISTRY
+
+
 def test_mask_generation_matches_golden(golden_dir):
     import os
     from diffmusic_amd.inverse_problem.operator import MusicInpaintingOperator
