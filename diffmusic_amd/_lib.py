@@ -49,11 +49,13 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_float), ("act_slope", C.c_float), ("mask_slope", C.c_float),
                 ("flags", C.c_int),
                 ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ldrb", C.c_int), ("ksplit", C.c_int),
-                ("XB", C.c_void_p), ("B2", C.c_void_p), ("ldxb", C.c_int), ("ldb2", C.c_int)]
+                ("XB", C.c_void_p), ("B2", C.c_void_p), ("ldxb", C.c_int), ("ldb2", C.c_int),
+                ("colsum", C.c_void_p), ("ln_eps", C.c_float)]
 
 
 EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV, EPI_MASKBITS, EPI_BITS2, EPI_SOFTBWD = \
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
+EPI_GEGLU, EPI_LNFOLD = 8192, 16384
 
 _SIGS = {
     "dmx_abi_version": (C.c_int, []),
@@ -146,7 +148,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 2          # include/diffmusic_hip.h DMX_ABI_VERSION
+ABI_VERSION = 3          # include/diffmusic_hip.h DMX_ABI_VERSION
 
 
 def act_dtype():

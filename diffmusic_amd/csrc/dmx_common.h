@@ -106,6 +106,9 @@ enum {
   EPI_GEGLU = 8192,    // GEGLU of a feed-forward's first projection fused into its epilogue: the weight rows are packed in blocks of
                        // 32 = [16 value rows | their 16 gate rows], so accumulator fragments 2t / 2t + 1 of a wave hold value and gate of
                        // the same 16 channels: out[row, 16 t' + c] = (v + bias) * gelu_erf(g + bias), N / 2 output columns (ld = ldc)
+  EPI_LNFOLD = 16384,  // LayerNorm of the input rows folded into this projection (single tap, K = the normalised width): the kernel gathers
+                       // mean / rstd of every row from the activation fragments in its K loop and the accumulators become
+                       // rstd * (acc - mean * colsum[n]) before the rest of the epilogue; W carries gamma, bias carries W beta (pack_layer)
   EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
                        // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };
@@ -138,9 +141,13 @@ struct GemmDesc {
   const unsigned char* XB;   // EPI_MASKBITS source, row stride ldxb bytes (rows indexed like C; Z must be 1)
   unsigned char* B2;         // EPI_BITS2 destination, row stride ldb2 bytes
   int ldxb, ldb2;
+  const float* colsum;       // EPI_LNFOLD: sum over k of the packed (gamma-folded, 16-bit rounded) weight row, fp32 [N]
+  float ln_eps;              // EPI_LNFOLD: LayerNorm epsilon
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);
 void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes);
 void dmx_gemm_release_splitk_workspace(const float* ws);
+// EPI_LNFOLD launches (gemm_ln.hip): tile configuration `cfg` as numbered in gemm_conv.hip, mapped onto the instantiated subset
+int dmx_gemm_launch_ln(int cfg, const GemmDesc& d, hipStream_t stream);
 bool dmx_prof_is_active();

@@ -61,6 +61,11 @@ struct ConvLayer {
   bool geglu = false;       // linear layer whose output is [values | gates]: rows packed in blocks of 32 = [16 values | their 16 gates]
                             // (bias likewise) so that the GEMM epilogue can apply GEGLU (EPI_GEGLU); forward only
   int w_id = -1, b_id = -1;
+  // LayerNorm folded into this linear layer (forward only): parameter ids of the norm's weight / bias.  pack_layer then packs W diag(gamma),
+  // adds W beta to the bias and keeps the row sums of the packed matrix; linear_fwd runs it on the RAW (un-normalised) rows with EPI_LNFOLD
+  int ln_g_id = -1, ln_b_id = -1;
+  float ln_eps = 1e-5f;
+  float* colsum = nullptr;          // fp32 [Cop]
   // packed
   std::vector<act_t*> wf;          // forward weights (one per output phase for transposed)
   std::vector<std::vector<int>> wf_taps;  // tap index list per phase (transposed)

@@ -78,6 +78,29 @@ __global__ void pad_bias_kernel(const float* __restrict__ src, float* __restrict
   if (i < np) dst[i] = (src && s < n) ? src[s] : 0.f;
 }
 
+// LayerNorm fold (ConvLayer::ln_g_id): Wf[n][k] = W[n][k] * gamma[k], bf[n] = bias[n] + sum_k W[n][k] * beta[k]   (fp32; one block per row)
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ bias, float* __restrict__ Wf, float* __restrict__ bf, int K) {
+  __shared__ float sh[16];
+  const int n = blockIdx.x;
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float w = W[(long long)n * K + k];
+    Wf[(long long)n * K + k] = w * gamma[k];
+    acc += w * beta[k];
+  }
+  acc = block_sum(acc, sh);
+  if (threadIdx.x == 0) bf[n] = (bias ? bias[n] : 0.f) + acc;
+}
+// colsum[p] = sum_k of the PACKED 16-bit row p (what the MFMAs multiply by; fixed summation order: bit-reproducible); one wave per row
+__global__ __launch_bounds__(64) void packed_rowsum_kernel(const act_t* __restrict__ Wp, float* __restrict__ colsum, int Kp) {
+  const int p = blockIdx.x, lane = threadIdx.x;
+  float acc = 0.f;
+  for (int k = lane; k < Kp; k += 64) acc += a2f(Wp[(long long)p * Kp + k]);
+  acc = wave_sum(acc);
+  if (lane == 0) colsum[p] = acc;
+}
+
 static act_t* pack(ParamStore& ps, const float* src, int Np, int Nreal, int T, int Cp, int Creal, long long sn, long long sc,
                     long long st_, const std::vector<int>& tapidx, hipStream_t st, int geglu_half = 0) {
   const long long total = (long long)Np * T * Cp;
@@ -211,6 +234,17 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
     if (L.transposed || T != 1 || L.need_bwd || (L.Co & 31) || L.Cop != L.Co) { dmx_set_error("GEGLU packing needs a forward-only linear layer with Cout %% 32 == 0"); return DMX_ERR_SHAPE; }
     gh = L.Co / 2;
   }
+  float* ln_w = nullptr;       // LayerNorm fold: temporary fp32 W diag(gamma) and the folded bias
+  float* ln_bias = nullptr;
+  if (L.ln_g_id >= 0) {
+    if (L.transposed || T != 1 || L.need_bwd) { dmx_set_error("LayerNorm fold needs a forward-only linear layer"); return DMX_ERR_SHAPE; }
+    if (hipMalloc(&ln_w, (size_t)L.Co * L.Ci * sizeof(float)) != hipSuccess) return DMX_ERR_PARAM;
+    ln_bias = (float*)ps.dalloc((size_t)L.Co * sizeof(float));
+    if (!ln_bias) { (void)hipFree(ln_w); return DMX_ERR_PARAM; }
+    hipLaunchKernelGGL(ln_fold_kernel, dim3(L.Co), dim3(256), 0, st, w, ps.dev(L.ln_g_id), ps.dev(L.ln_b_id),
+                       L.has_bias ? ps.dev(L.b_id) : (const float*)nullptr, ln_w, ln_bias, L.Ci);
+    w = ln_w;
+  }
   if (!L.transposed) {
     // W[Co][Ci][T]
     L.wf.push_back(pack(ps, w, L.Cop, L.Co, T, L.Cip, L.Ci, (long long)L.Ci * T, T, 1, all, st, gh));
@@ -228,9 +262,17 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
     if (L.need_bwd) L.wb = pack(ps, w, L.Cip, L.Ci, k, L.Cop, L.Co, (long long)L.Co * k, k, 1, all, st);
   }
   L.bias = (float*)ps.dalloc(L.Cop * sizeof(float));
-  hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(L.Cop, 256)), dim3(256), 0, st, L.has_bias ? ps.dev(L.b_id) : (const float*)nullptr,
-                     L.bias, L.Co, L.Cop, gh);
-  for (act_t* pw : L.wf) if (!pw) return DMX_ERR_PARAM;
+  hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(L.Cop, 256)), dim3(256), 0, st,
+                     ln_bias ? (const float*)ln_bias : (L.has_bias ? ps.dev(L.b_id) : (const float*)nullptr), L.bias, L.Co, L.Cop, gh);
+  for (act_t* pw : L.wf) if (!pw) { if (ln_w) (void)hipFree(ln_w); return DMX_ERR_PARAM; }
+  if (ln_w) {
+    L.has_bias = true;                      // W beta (zero when beta is)
+    L.colsum = (float*)ps.dalloc(L.Cop * sizeof(float));
+    if (!L.colsum) { (void)hipFree(ln_w); return DMX_ERR_PARAM; }
+    hipLaunchKernelGGL(packed_rowsum_kernel, dim3(L.Cop), dim3(64), 0, st, L.wf[0], L.colsum, L.Cip);
+    (void)hipStreamSynchronize(st);         // model-load time: the temporary is read by the kernels above
+    (void)hipFree(ln_w);
+  }
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
@@ -425,6 +467,7 @@ int linear_fwd(const ConvLayer& L, const act_t* in, int lda, void* out, int ldc,
   d.N = L.Cop; d.Hq = 1; d.Wq = (int)rows; d.M = (int)rows;
   set_out(d, out, 1, (int)rows, ldc);
   if (L.geglu) d.flags |= EPI_GEGLU;          // out is (rows, Cop / 2): value * gelu(gate), applied in the epilogue
+  if (L.colsum) { d.flags |= EPI_LNFOLD; d.colsum = L.colsum; d.ln_eps = L.ln_eps; }     // `in` holds the RAW rows: LayerNorm happens inside
   return dmx_gemm_launch(d, st);
 }
 int linear_bwd(const ConvLayer& L, const act_t* dout, int lda, void* din, int ldc, long long rows, const Epi& e, hipStream_t st) {

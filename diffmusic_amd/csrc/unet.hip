@@ -41,6 +41,22 @@ struct AttnLayer {
       to_qkv.Co = to_qkv.Cop = 3 * C;
       to_qkv.wf.assign(1, w);
       to_qkv.has_bias = false;
+      to_qkv.bias = nullptr;
+      to_qkv.colsum = nullptr;
+      if (to_q.colsum && to_k.colsum && to_v.colsum) {
+        // LayerNorm folded into all three (self-attention): stack the row sums and the folded biases (W beta) like the weights
+        float* cs = (float*)ps.dalloc(3 * (size_t)C * sizeof(float));
+        float* bs = (float*)ps.dalloc(3 * (size_t)C * sizeof(float));
+        if (!cs || !bs) return DMX_ERR_PARAM;
+        const ConvLayer* src[3] = {&to_q, &to_k, &to_v};
+        for (int i = 0; i < 3; ++i) {
+          (void)hipMemcpyAsync(cs + (size_t)i * C, src[i]->colsum, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(bs + (size_t)i * C, src[i]->bias, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+        }
+        to_qkv.colsum = cs; to_qkv.bias = bs; to_qkv.has_bias = true;
+      } else if (to_q.colsum || to_k.colsum || to_v.colsum) {
+        return DMX_OK;           // (mixed: cannot happen for self-attention; leave the three projections unstacked)
+      }
       fused = getenv("DMX_NO_QKV_FUSE") == nullptr;
     }
     return DMX_OK;
@@ -102,7 +118,18 @@ struct Transformer2D {
     ff1.geglu = ((ch * 8) % 32 == 0) && getenv("DMX_NO_GEGLU_FUSE") == nullptr;     // GEGLU in the projection's epilogue (no 8C-wide tensor)
     ff2 = make_linear(ps, tb + ".ff.net.2", ch * 4, ch, true, false);
     proj_out = make_conv2d(ps, pre + ".proj_out", ch, ch, 1, 1, 0, false);
+    // LayerNorm folded into the projections that consume it (EPI_LNFOLD): norm1 -> attn1 q/k/v, norm2 -> attn2 q (and k/v when attn2 is
+    // self-attention), norm3 -> ff1.  The three layernorm launches and their normalised tensors disappear.
+    ln_fold = getenv("DMX_NO_LN_FOLD") == nullptr && (ch % 8) == 0;
+    if (ln_fold) {
+      auto fold = [](ConvLayer& L, const LnParams& ln) { L.ln_g_id = ln.g_id; L.ln_b_id = ln.b_id; L.ln_eps = 1e-5f; };
+      fold(attn1.to_q, ln1); fold(attn1.to_k, ln1); fold(attn1.to_v, ln1);
+      fold(attn2.to_q, ln2);
+      if (cross == 0) { fold(attn2.to_k, ln2); fold(attn2.to_v, ln2); }
+      fold(ff1, ln3);
+    }
   }
+  bool ln_fold = false;
   int pack(ParamStore& ps, hipStream_t st) {
     norm.bind(ps); ln1.bind(ps); ln2.bind(ps); ln3.bind(ps);
     CTRY(pack_layer(ps, proj_in, st)); CTRY(pack_layer(ps, proj_out, st));
@@ -123,20 +150,23 @@ struct Transformer2D {
     CTRY(norm.fwd(cx, x, n, B, N, 0, gt));
     Epi e;
     CRUN(conv_fwd_2d(proj_in, n, hbuf, B, H, W, e, cx.st));
-    CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
-    CTRY(attn1.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));
-    CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
-    if (cross > 0) CTRY(attn2.fwd(cx, l, ctx, Nc, hbuf, B, N, colbias, kv_pre, ldkv));
-    else CTRY(attn2.fwd(cx, l, nullptr, 0, hbuf, B, N, nullptr));   // encoder_hidden_states=None -> self-attention
-    CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
+    // (ln_fold: the projections read the raw hidden state `hbuf` and normalise inside; they finish before the out-projection's
+    //  residual epilogue rewrites hbuf -- launches of one stream run in order)
+    const act_t* lin = ln_fold ? hbuf : l;
+    if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
+    CTRY(attn1.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr));
+    if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
+    if (cross > 0) CTRY(attn2.fwd(cx, lin, ctx, Nc, hbuf, B, N, colbias, kv_pre, ldkv));
+    else CTRY(attn2.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr));   // encoder_hidden_states=None -> self-attention
+    if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
     {
       const size_t mk2 = A.mark();
       act_t* gg = A.bf((size_t)B * N * C * 4);
       if (ff1.geglu) {
-        CRUN(linear_fwd(ff1, l, C, gg, C * 4, (long long)B * N, e, cx.st));       // [values | gates] -> values * gelu(gates) in the epilogue
+        CRUN(linear_fwd(ff1, lin, C, gg, C * 4, (long long)B * N, e, cx.st));       // [values | gates] -> values * gelu(gates) in the epilogue
       } else {
         act_t* f = A.bf((size_t)B * N * C * 8);
-        CRUN(linear_fwd(ff1, l, C, f, C * 8, (long long)B * N, e, cx.st));
+        CRUN(linear_fwd(ff1, lin, C, f, C * 8, (long long)B * N, e, cx.st));
         CRUN(dmx_geglu(f, gg, (long long)B * N, C * 4, cx.st));
       }
       Epi er; er.flags = EPI_RESID; er.R = hbuf;

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 2   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew */
+#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD: colsum, ln_eps) */
 #define DMX_MAX_STAGES 8
 
 typedef struct dmx_model dmx_model; /* opaque network handle (weights repacked for MFMA) */

@@ -428,3 +428,33 @@ def test_sign_bit_tape_forward_and_backward(B, T, Cc, k, dil):
             _run(L, eb)
         res[mode] = dst
     assert torch.equal(res["full"], res["bits"])
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 10, 11, 12, 13, 14, 18, 3, 4, 6])
+@pytest.mark.parametrize("M,K,N", [(1000, 320, 384), (4032, 384, 1152), (333, 200, 72)])
+def test_layernorm_fold_gemm(cfg, M, K, N):
+    """EPI_LNFOLD: out = LayerNorm(x) W^T + b computed by ONE GEMM on the raw rows -- row statistics gathered from the activation
+    fragments in the K loop, gamma folded into the packed weights, beta into the bias, and the accumulators corrected with the
+    packed row sums (csrc/gemm_tile.h ln_acc / ln_apply; the U-Net's LN -> QKV / FF1 pairs).  Every instantiated tile, K with a
+    partial last 64-channel group, M / N tails; rows with a large common offset (mean >> std) stress the mean * colsum cancellation."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(100 + cfg)
+    x = (torch.randn(M, K, generator=g) * (0.2 + torch.rand(M, 1, generator=g)) + 3.0 * torch.randn(M, 1, generator=g)).to(_adt())
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    gamma, beta = 0.5 + torch.rand(K, generator=g), 0.3 * torch.randn(K, generator=g)
+    bias = 0.1 * torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(_adt())
+    wf = (w * gamma).to(_adt())                                   # what pack_layer packs
+    colsum = wf.float().sum(1).contiguous()
+    bf = (bias + w @ beta).contiguous()
+    out = torch.empty(M, N, dtype=_adt(), device="cuda")
+    xd, wd, rd, cd, bd = x.cuda(), wf.cuda(), res.cuda(), colsum.cuda(), bf.cuda()
+    d = _desc(L, A=xd, W=wd, C=out, bias=bd, R=rd, colsum=cd, ln_eps=1e-5, M=M, N=N, K=K, ldw=K, Hi=1, Wi=M, Ci=K, lda=K, Hq=1, Wq=M,
+              ntaps=1, Ho=1, Wo=M, ldc=N, ldr=N, ldx=N, ldc2=N, flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_LNFOLD, tdy=[0], tdx=[0], tile_cfg=cfg)
+    _run(L, d)
+    ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + bias + res.float()
+    err = _rel(out.cpu(), ref)
+    assert err < 4e-3, err
+    # a split-K plan cannot carry the fold (every wave must see all of K): the forced plan is refused, not silently mis-normalised
+    d.tile_cfg = 212
+    assert L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0

@@ -57,3 +57,49 @@ def test_audioldm2_unet_fwd_vs_oracle():
         oref = ref(x, 501, encoder_hidden_states=c0, encoder_hidden_states_1=c1, encoder_attention_mask_1=mask)[0]
     print("rel eps (audioldm2)", _rel(out.cpu(), oref))
     assert _rel(out.cpu(), oref) < 1e-2
+
+
+@pytest.mark.parametrize("cfg_name", ["musicldm", "audioldm2"])
+def test_layernorm_fold_matches_oracle_and_unfused_path(cfg_name, monkeypatch):
+    """EPI_LNFOLD (LayerNorm folded into the QKV / Q / FF1 projections, csrc/gemm_tile.h): with strongly non-trivial LayerNorm weights
+    and biases the folded U-Net stays at the oracle's level and agrees with the same engine built with the fold switched off
+    (separate layernorm launches) to 16-bit rounding."""
+    from diffmusic_amd.engine import UNetEngine
+    from oracle.models import UNetMusicLDM
+    cfg = SMALL if cfg_name == "musicldm" else A2
+    eng = UNetEngine(cfg)
+    sd = eng.synth_state_dict(seed=13)
+    g = torch.Generator().manual_seed(77)
+    n_ln = 0
+    for k in sd:
+        if ".transformer_blocks.0.norm" in k:
+            n_ln += 1
+            sd[k] = (0.5 + torch.rand(sd[k].shape, generator=g)) if k.endswith("weight") else 0.3 * torch.randn(sd[k].shape, generator=g)
+    assert n_ln >= 6
+    eng.load_state_dict(sd)
+    monkeypatch.setenv("DMX_NO_LN_FOLD", "1")
+    eng_plain = UNetEngine(cfg)
+    eng_plain.load_state_dict(sd)
+    monkeypatch.delenv("DMX_NO_LN_FOLD")
+    B = 2
+    x = torch.randn(B, 8, 26, 16, generator=g)
+    if cfg_name == "musicldm":
+        cls = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
+        args = (x.cuda(), torch.full((B,), 501.0), cls.cuda())
+        ref = UNetMusicLDM(**SMALL)
+        okw = dict(class_labels=cls)
+    else:
+        c0, c1 = torch.randn(B, 8, 48, generator=g), torch.randn(B, 12, 64, generator=g)
+        args = (x.cuda(), torch.full((B,), 501.0), None, c0.cuda(), c1.cuda(), torch.ones(B, 12).cuda())
+        ref = UNetMusicLDM(**{k: v for k, v in A2.items() if k != "attn_cross_dims"}, attn_cross_dims=(None, 48, 64))
+        okw = dict(encoder_hidden_states=c0, encoder_hidden_states_1=c1, encoder_attention_mask_1=torch.ones(B, 12))
+    ref.load_state_dict(sd, strict=True)
+    out, out_plain = eng.forward(*args), eng_plain.forward(*args)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        oref = ref(x, 501, **okw)[0]
+    print(f"LN fold ({cfg_name}): folded vs oracle {_rel(out.cpu(), oref):.2e}, unfused vs oracle {_rel(out_plain.cpu(), oref):.2e}, "
+          f"folded vs unfused {_rel(out, out_plain):.2e}")
+    assert _rel(out.cpu(), oref) < 1e-2 and _rel(out_plain.cpu(), oref) < 1e-2
+    assert _rel(out, out_plain) < 5e-3
+    assert not torch.equal(out, out_plain)          # the two engines really take different paths
