@@ -20,6 +20,38 @@ struct Ctx {           // per-call execution context
 
 struct GnTape { float* stats = nullptr; float* scale = nullptr; float* shift = nullptr; };
 
+// ---- GroupNorm partial sums written by the producers of a tensor (EPI_GNSTATS; kernels.h GnParts): a tensor that will be normalised
+// travels with a GnParts: n > 0 = valid regions, 0 = none requested, -1 = a producer could not provide them (the GroupNorm then makes its
+// own statistics pass).  Buffers live in the arena next to the tensor they describe.
+inline bool gn_parts_wanted(size_t P) {
+  const bool on = getenv("DMX_NO_GN_PARTS") == nullptr;      // (read per call: tests compare both paths in one process)
+  return on && P > 512;                   // (<= 512 pixels: the single-launch gn_small plan, which needs no partial sums)
+}
+inline float* gn_part_alloc(Ctx& cx, int B, size_t P, int Np) { return cx.arena->f32(dmx_gn_part_floats(B, (int)P, Np)); }
+// after the launch that carried EPI_GNSTATS into `buf` (`tm` = dmx_gemm_last_tile_rows() of it; dry runs record a placeholder)
+inline void gn_parts_push(Ctx& cx, GnParts* gp, float* buf, int tm, int P, int Np, int Creal, int qoff = 0) {
+  if (!gp || gp->n < 0) return;
+  if (cx.dry) tm = 32;
+  if (tm > 0 && gp->n < 8) gp->r[gp->n++] = GnRegion{buf, tm, P, Np / 4, qoff, Creal / 4};
+  else gp->n = -1;
+}
+inline GnParts gn_parts_concat(const GnParts& a, const GnParts& b, int Ca) {       // [a | b] along the channels (a has Ca channels)
+  GnParts o;
+  if (a.n <= 0 || b.n <= 0 || a.n + b.n > 8) { o.n = -1; return o; }
+  for (int i = 0; i < a.n; ++i) o.r[o.n++] = a.r[i];
+  for (int i = 0; i < b.n; ++i) { o.r[o.n] = b.r[i]; o.r[o.n++].qoff += Ca / 4; }
+  return o;
+}
+inline const GnParts* gn_parts_valid(const GnParts* p) { return p && p->n > 0 ? p : nullptr; }
+// a fresh GnParts for a tensor of B x P pixels x Np (padded) channels about to be produced: buffer in r[0].part, n = 0; n = -1 when
+// the consumer's GroupNorm would not use partial sums anyway
+inline GnParts gn_parts_new(Ctx& cx, int B, size_t P, int Np) {
+  GnParts g;
+  if (gn_parts_wanted(P)) g.r[0].part = gn_part_alloc(cx, B, P, Np); else g.n = -1;
+  return g;
+}
+inline float* gn_parts_buf(const GnParts& g) { return g.n == 0 ? g.r[0].part : nullptr; }
+
 struct GnLayer {
   GroupNormLayer g;
   const float* gamma = nullptr;
@@ -33,8 +65,9 @@ struct GnLayer {
     t.shift = cx.arena->f32((size_t)B * g.C);
     return t;
   }
-  int fwd(Ctx& cx, const act_t* x, act_t* y, int B, int P, int silu, const GnTape& t) const {
-    CRUN(dmx_groupnorm_fwd(x, y, gamma, beta, t.stats, t.scale, t.shift, cx.gn_partial, B, P, g.C, g.G, g.eps, silu, cx.st));
+  int fwd(Ctx& cx, const act_t* x, act_t* y, int B, int P, int silu, const GnTape& t, const GnParts* parts = nullptr) const {
+    CRUN(dmx_groupnorm_fwd(x, y, gamma, beta, t.stats, t.scale, t.shift, cx.gn_partial, B, P, g.C, g.G, g.eps, silu, cx.st,
+                           gn_parts_valid(parts)));
     return DMX_OK;
   }
   int bwd(Ctx& cx, const act_t* x, const act_t* dy, const act_t* add, act_t* dx, int B, int P, int silu, const GnTape& t) const {
@@ -75,8 +108,10 @@ struct Resnet2D {
   // x (B,H,W,Cin) -> out (B,H,W,Cout) (caller-allocated).  silu_emb (B, temb_ch) fp16, already SiLU'd.
   // tape != nullptr keeps what backward() needs (persistent arena allocations).
   // rb_pre / ldrb: this block's slice of a time-embedding projection computed for all blocks in one GEMM (U-Net)
+  // x_parts: partial sums of x from its producers (norm1 then skips its statistics pass); out_parts: the caller's GnParts for `out` with
+  // r[0].part pointing at a buffer of dmx_gn_part_floats(B, P, pad8(Cout)) floats -- conv2 fills it (n = 1) or marks it invalid (n = -1)
   int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* silu_emb, ResnetTape* tape,
-          const float* rb_pre = nullptr, int ldrb = 0) const {
+          const float* rb_pre = nullptr, int ldrb = 0, const GnParts* x_parts = nullptr, GnParts* out_parts = nullptr) const {
     Arena& A = *cx.arena;
     const size_t P = (size_t)H * W;
     ResnetTape t;
@@ -85,8 +120,10 @@ struct Resnet2D {
     const size_t mk = A.mark();
     if (!tape) { t.h1 = A.bf(B * P * Cout); t.g1 = norm1.alloc(cx, B); t.g2 = norm2.alloc(cx, B); }
     act_t* n = A.bf(B * P * (Cin > Cout ? Cin : Cout));
-    CTRY(norm1.fwd(cx, x, n, B, (int)P, 1, t.g1));
+    CTRY(norm1.fwd(cx, x, n, B, (int)P, 1, t.g1, x_parts));
     Epi e1;
+    GnParts h1p;
+    float* h1buf = gn_parts_wanted(P) ? gn_part_alloc(cx, B, P, conv1.Cop) : nullptr;      // conv1 -> norm2
     if (has_temb && rb_pre) {
       e1.flags = EPI_ROWBIAS; e1.rowbias = rb_pre; e1.ldrb = ldrb;
     } else if (has_temb) {
@@ -95,8 +132,10 @@ struct Resnet2D {
       CRUN(linear_fwd(temb, silu_emb, temb.Cip, rb, Cout, B, et, cx.st));
       e1.flags = EPI_ROWBIAS; e1.rowbias = rb;
     }
+    e1.gn_part = h1buf;
     CRUN(conv_fwd_2d(conv1, n, t.h1, B, H, W, e1, cx.st));
-    CTRY(norm2.fwd(cx, t.h1, n, B, (int)P, 1, t.g2));
+    if (h1buf) gn_parts_push(cx, &h1p, h1buf, cx.dry ? 0 : dmx_gemm_last_tile_rows(), (int)P, conv1.Cop, Cout);
+    CTRY(norm2.fwd(cx, t.h1, n, B, (int)P, 1, t.g2, &h1p));
     Epi e2; e2.flags = EPI_RESID; e2.R = x;
     if (has_shortcut) {
       act_t* sc = A.bf(B * P * Cout);
@@ -104,7 +143,10 @@ struct Resnet2D {
       CRUN(conv_fwd_2d(shortcut, x, sc, B, H, W, es, cx.st));
       e2.R = sc;
     }
+    float* obuf = out_parts ? gn_parts_buf(*out_parts) : nullptr;
+    e2.gn_part = obuf;
     CRUN(conv_fwd_2d(conv2, n, out, B, H, W, e2, cx.st));
+    if (obuf) gn_parts_push(cx, out_parts, obuf, cx.dry ? 0 : dmx_gemm_last_tile_rows(), (int)P, conv2.Cop, Cout);
     A.release(mk);
     if (tape) *tape = t;
     return DMX_OK;

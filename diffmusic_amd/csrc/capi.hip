@@ -147,4 +147,22 @@ int dmx_groupnorm_raw(const void* x, void* y, const float* gamma, const float* b
   return rc;
 }
 
+// GroupNorm from producer-written partial sums (EPI_GNSTATS regions, see kernels.h GnParts / gn_parts_kernel): test hook.
+// regions: nreg x 6 ints {tm, P, nq, qoff, cq, 0} and nreg buffer pointers.
+size_t dmx_groupnorm_part_floats(int B, int P, int N) { return dmx_gn_part_floats(B, P, N); }
+int dmx_groupnorm_parts_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
+                            int B, int P, int C, int G, float eps, int silu, int nreg, float* const* part, const int* geom, void* stream) {
+  if (nreg < 1 || nreg > 8) { dmx_set_error("groupnorm_parts: 1..8 regions"); return DMX_ERR_SHAPE; }
+  GnParts gp;
+  for (int i = 0; i < nreg; ++i) {
+    GnRegion r;
+    r.part = part[i]; r.tm = geom[i * 6]; r.P = geom[i * 6 + 1]; r.nq = geom[i * 6 + 2]; r.qoff = geom[i * 6 + 3]; r.cq = geom[i * 6 + 4];
+    gp.r[gp.n++] = r;
+  }
+  const int rc = dmx_groupnorm_fwd((const act_t*)x, (act_t*)y, gamma, beta, stats, scale, shift, nullptr, B, P, C, G, eps, silu, ST(stream), &gp);
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("groupnorm: unsupported channel / group counts");
+  return rc;
+}
+int dmx_gemm_last_tile_rows_raw(void) { return dmx_gemm_last_tile_rows(); }
+
 }  // extern "C"

@@ -106,9 +106,14 @@ enum {
   EPI_GEGLU = 8192,    // GEGLU of a feed-forward's first projection fused into its epilogue: the weight rows are packed in blocks of
                        // 32 = [16 value rows | their 16 gate rows], so accumulator fragments 2t / 2t + 1 of a wave hold value and gate of
                        // the same 16 channels: out[row, 16 t' + c] = (v + bias) * gelu_erf(g + bias), N / 2 output columns (ld = ldc)
-  EPI_LNFOLD = 16384,  // LayerNorm of the input rows folded into this projection (single tap, K = the normalised width): the kernel gathers
-                       // mean / rstd of every row from the activation fragments in its K loop and the accumulators become
+  EPI_LNFOLD = 16384,  // LayerNorm of the input rows folded into this projection (single tap, K = the normalised width): mean / rstd of every
+                       // row come from the partial sums its producer wrote (rowstats_in, EPI_ROWSTATS) and the accumulators become
                        // rstd * (acc - mean * colsum[n]) before the rest of the epilogue; W carries gamma, bias carries W beta (pack_layer)
+  EPI_ROWSTATS = 32768, // also write per-row partial sums (sum v, sum v^2 per 32-column slot, fp32) of the final values to rowstats_out
+                        // [row][nslots][2]: the statistics of a LayerNorm folded into the next projection (identity row map, N % 32 == 0)
+  EPI_GNSTATS = 65536,  // also write GroupNorm partial sums of the stored output to gn_part: (sum v, sum v^2) per 4-channel quad, per wave tile and
+                        // image -- [image][slot][N / 4][2] fp32 with slot = wave-tile index inside the image (rows per tile = the tile's TM,
+                        // reported by dmx_gemm_last_tile_rows()); the consumer's GroupNorm needs no statistics pass over the tensor
   EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
                        // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };
@@ -143,6 +148,10 @@ struct GemmDesc {
   int ldxb, ldb2;
   const float* colsum;       // EPI_LNFOLD: sum over k of the packed (gamma-folded, 16-bit rounded) weight row, fp32 [N]
   float ln_eps;              // EPI_LNFOLD: LayerNorm epsilon
+  const float* rowstats_in;  // EPI_LNFOLD: per-row partial sums [M][nslots][2] written by the producer of A (EPI_ROWSTATS)
+  float* rowstats_out;       // EPI_ROWSTATS destination [rows][nslots][2]
+  int nslots;                // 32-column slots per row of rowstats_in / rowstats_out
+  float* gn_part;            // EPI_GNSTATS destination
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);
@@ -150,4 +159,10 @@ void dmx_gemm_set_splitk_workspace(float* ws, size_t bytes);
 void dmx_gemm_release_splitk_workspace(const float* ws);
 // EPI_LNFOLD launches (gemm_ln.hip): tile configuration `cfg` as numbered in gemm_conv.hip, mapped onto the instantiated subset
 int dmx_gemm_launch_ln(int cfg, const GemmDesc& d, hipStream_t stream);
+int dmx_gemm_launch_rowstats(int cfg, const GemmDesc& d, hipStream_t stream);      // EPI_ROWSTATS producers (same file)
+int dmx_gemm_launch_gnstats(int cfg, const GemmDesc& d, hipStream_t stream);       // EPI_GNSTATS producers (gemm_gn.hip)
+// rows per wave tile (the TM of EPI_GNSTATS slots) of the most recent dmx_gemm_launch of this thread, 0 when that launch carried no
+// statistics (split-K plan, direct epilogue)
+int dmx_gemm_last_tile_rows();
+void dmx_gemm_reset_last_tile_rows();
 bool dmx_prof_is_active();

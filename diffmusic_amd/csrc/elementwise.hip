@@ -338,6 +338,178 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const act_t* __r
   for (; p < p1; p += rpb) body(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), base + (long long)p * C);
 }
 
+// ---- GroupNorm from PRODUCER-written partial sums (EPI_GNSTATS, gemm_epilogue.h): no statistics pass over the tensor.
+// A region = the partial sums one producer launch left for (part of) the normalised tensor: per image, per wave tile of `tm` GEMM rows
+// (slot j = tile index inside the image; a tile that straddles two images is the last slot of one and slot 0 of the next), per 4-channel
+// quad: (sum v, sum v^2) of the stored 16-bit values.  Up to 8 regions make up a tensor: the four output-parity launches of an
+// upsample-folded convolution (each covers a quarter of the pixels), the two sources of a skip concatenation (qoff = quad offset of the
+// source's channel 0 in the normalised tensor; a group may straddle the seam).  Every (region, slot, group) item becomes (n, mean, M2) --
+// M2 = sum v^2 - (sum v)^2 / n over at most tm x C/G values -- and the items are Chan-combined in two sweeps (mean first, then
+// M2 + n (mean_i - mean)^2), like the chunk partials of gn_partial_kernel / gn_finalize_kernel.
+// rows of image b inside slot j of region R, and the slot count of image b
+__device__ __forceinline__ int gn_parts_rows(const GnRegion& R, int b, int j) {
+  const int k = j + (b * R.P) / R.tm;
+  const int lo = max(k * R.tm, b * R.P), hi = min((k + 1) * R.tm, (b + 1) * R.P);
+  return hi > lo ? hi - lo : 0;
+}
+__device__ __forceinline__ int gn_parts_nslots(const GnRegion& R, int b) {
+  return ((b + 1) * R.P - 1) / R.tm - (b * R.P) / R.tm + 1;
+}
+// quads [q0, q1) of region R that belong to group g (cpg channels per group)
+__device__ __forceinline__ void gn_parts_quads(const GnRegion& R, int g, int cpg, int& q0, int& q1) {
+  const int gq0 = (g * cpg) >> 2, gq1 = ((g + 1) * cpg) >> 2;
+  q0 = max(gq0, R.qoff) - R.qoff;
+  q1 = min(gq1, R.qoff + R.cq) - R.qoff;
+}
+// Block-wide: (mean, rstd) of every group of image b into s_mean / s_rstd.  Thread t < (nth / G) * G owns group t % G and the slots
+// t / G, t / G + nth / G, ... of every region.  STAGED: the image's partial sums were copied to LDS first (`s_buf`, region r at float2
+// offset soff[r], slot-major like the global layout) -- one coalesced round trip for the whole workgroup instead of a dependent load per
+// item (the direct form cost the fused mid-size plan 8 us per launch).  `s_red` holds nth floats.
+template <bool STAGED>
+__device__ __forceinline__ void gn_parts_combine(const GnParts& sp, int b, int C, int G, float eps, float* s_red, float* s_mean, float* s_rstd,
+                                                 const float2* s_buf, const int* soff) {
+  const int tid = threadIdx.x, nth = blockDim.x, nslice = nth / G, cpg = C / G;
+  const bool act = tid < nslice * G;
+  const int g = tid % G, slice = tid / G;
+  auto sweep = [&](auto&& f) {
+    if (!act) return;
+    for (int r = 0; r < sp.n; ++r) {
+      const GnRegion& R = sp.r[r];
+      int q0, q1;
+      gn_parts_quads(R, g, cpg, q0, q1);
+      if (q1 <= q0) continue;
+      const int ns = gn_parts_nslots(R, b), slots = (R.P + R.tm - 1) / R.tm + 1;
+      const float2* src = STAGED ? s_buf + soff[r] : reinterpret_cast<const float2*>(R.part) + (long long)b * slots * R.nq;
+      for (int j = slice; j < ns; j += nslice) {
+        const int rows = gn_parts_rows(R, b, j);
+        if (rows <= 0) continue;
+        float sv = 0.f, qv = 0.f;
+        for (int q = q0; q < q1; ++q) { const float2 v = src[j * R.nq + q]; sv += v.x; qv += v.y; }
+        f(sv, qv, (float)rows * 4.f * (float)(q1 - q0));
+      }
+    }
+  };
+  auto reduce = [&](float v) -> float {        // sum over the slices of a group; result valid in threads < G
+    __syncthreads();
+    if (act) s_red[slice * G + g] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (tid < G) for (int k = 0; k < nslice; ++k) t += s_red[k * G + tid];
+    return t;
+  };
+  float a = 0.f, n = 0.f;
+  sweep([&](float sv, float qv, float nv) { a += sv; n += nv; });
+  const float st = reduce(a), nt = reduce(n);
+  if (tid < G) s_mean[tid] = st / fmaxf(nt, 1.f);
+  __syncthreads();
+  const float mean = s_mean[g];
+  float m2 = 0.f;
+  sweep([&](float sv, float qv, float nv) {
+    const float mi = sv / nv, d = mi - mean;
+    m2 += fmaxf(qv - sv * mi, 0.f) + nv * d * d;
+  });
+  const float m2t = reduce(m2);
+  if (tid < G) s_rstd[tid] = rsqrtf(m2t / fmaxf(nt, 1.f) + eps);
+  __syncthreads();
+}
+
+// grid (nchunk, B).  y != nullptr: finalize + apply in one launch (every workgroup repeats the small combine; workgroup 0 of an image also
+// writes stats / scale / shift for callers that keep a tape).  y == nullptr: statistics only (launched with one workgroup per image).
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_parts_kernel(const act_t* __restrict__ x, act_t* __restrict__ y, const GnParts sp,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ stats, float* __restrict__ scale, float* __restrict__ shift,
+                                                     int P, int C, int G, int rpb, int ppb, float eps, int silu, int stage_f2) {
+  __shared__ float s_red[NT];
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ int s_off[8];
+  extern __shared__ __attribute__((aligned(16))) float2 s_stage[];     // stage_f2 > 0: room for the image's partial sums (float2 count)
+  const int b = blockIdx.y, cpg = C / G, tid = threadIdx.x;
+  // what does not depend on the statistics is requested first (this thread's affine parameters and its first rows of x), so that one memory
+  // round trip covers them together with the partial sums
+  const int cpr = C >> 3;
+  const int col = tid % cpr, row = tid / cpr, c0 = col << 3;
+  const bool active = y && row < rpb;
+  const int p0 = blockIdx.x * ppb, p1 = min(P, p0 + ppb);
+  const long long base = (long long)b * P * C + c0;
+  float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, b0 = g0, b1 = g0;
+  uint4 xv0[4];
+  int p = p0 + row;
+  const bool first4 = active && p + 3 * rpb < p1;
+  if (active) {
+    g0 = *reinterpret_cast<const float4*>(gamma + c0); g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+    b0 = *reinterpret_cast<const float4*>(beta + c0); b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+    if (first4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv0[u] = *reinterpret_cast<const uint4*>(x + base + (long long)(p + u * rpb) * C);
+    }
+  }
+  if (stage_f2 > 0) {
+    int off = 0;
+    for (int r = 0; r < sp.n; ++r) {
+      const GnRegion& R = sp.r[r];
+      const int cnt = gn_parts_nslots(R, b) * R.nq, slots = (R.P + R.tm - 1) / R.tm + 1;
+      const float2* src = reinterpret_cast<const float2*>(R.part) + (long long)b * slots * R.nq;
+      // batches of 8 loads per thread in flight (a load-then-store loop waits for every load before its LDS write: one round trip each)
+      for (int i0 = 0; i0 < cnt; i0 += NT * 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + tid; v[u] = i < cnt ? src[i] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * NT + tid; if (i < cnt) s_stage[off + i] = v[u]; }
+      }
+      if (tid == 0) s_off[r] = off;
+      off += cnt;
+    }
+    __syncthreads();
+    gn_parts_combine<true>(sp, b, C, G, eps, s_red, s_mean, s_rstd, s_stage, s_off);
+  } else {
+    gn_parts_combine<false>(sp, b, C, G, eps, s_red, s_mean, s_rstd, nullptr, nullptr);
+  }
+  if (blockIdx.x == 0) {
+    if (tid < G) { stats[((long long)b * G + tid) * 2] = s_mean[tid]; stats[((long long)b * G + tid) * 2 + 1] = s_rstd[tid]; }
+    for (int c = tid; c < C; c += NT) {
+      const float a = s_rstd[c / cpg] * gamma[c];
+      scale[(long long)b * C + c] = a;
+      shift[(long long)b * C + c] = beta[c] - s_mean[c / cpg] * a;
+    }
+  }
+  if (!active) return;
+  float sc[8], sf[8];
+  {
+    const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int gg = (c0 + i) / cpg;
+      sc[i] = s_rstd[gg] * ga[i];
+      sf[i] = be[i] - s_mean[gg] * sc[i];
+    }
+  }
+  auto body = [&](const uint4& xv, long long off) {
+    float f[8];
+    unpack8(xv, f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float z = f[i] * sc[i] + sf[i];
+      f[i] = silu ? silu_f(z) : z;
+    }
+    *reinterpret_cast<uint4*>(y + off) = pack8(f);
+  };
+  if (first4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(xv0[u], base + (long long)(p + u * rpb) * C);
+    p += 4 * rpb;
+  }
+  for (; p + 3 * rpb < p1; p += 4 * rpb) {
+    uint4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = *reinterpret_cast<const uint4*>(x + base + (long long)(p + u * rpb) * C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) body(xv[u], base + (long long)(p + u * rpb) * C);
+  }
+  for (; p < p1; p += rpb) body(*reinterpret_cast<const uint4*>(x + base + (long long)p * C), base + (long long)p * C);
+}
+
 // backward finalize: per (b,c) coefficients k0, k1 with dx = scale*dy*act'(z) + k0 + k1*x
 __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __restrict__ partial, const float* __restrict__ stats,
                                        float* __restrict__ k0, float* __restrict__ k1,
@@ -920,14 +1092,43 @@ inline void gn_geom(int P, int C, int& nt, int& rpb, int& nchunk, int& ppb) {
 
 #define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH)
 
+size_t dmx_gn_part_floats(int B, int P, int N) { return (size_t)B * ((size_t)(P + 31) / 32 + 1) * (size_t)(N / 4) * 2; }
 size_t dmx_gn_scratch_floats(int B, int C, int G) {
   return (size_t)B * DMX_GN_MAX_CHUNKS * G * 2;
 }
 
 int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, float* stats, float* scale,
-                      float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st) {
+                      float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st, const GnParts* parts) {
   if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
   const int cpg = C / G;
+  if (parts && parts->n > 0 && (cpg & 3) == 0) {
+    // the producers of x left its partial sums (EPI_GNSTATS): combine them, no pass over x for the statistics
+    int nt, rpb, nchunk, ppb;
+    gn_geom(P, C, nt, rpb, nchunk, ppb);
+    // float2 elements of one image's partial sums (worst image: one slot more than P / tm)
+    long long f2 = 0;
+    for (int r = 0; r < parts->n; ++r) {
+      if ((long long)B * parts->r[r].P >= (1ll << 31) / 2) return DMX_ERR_SHAPE;        // (32-bit row arithmetic in the combine)
+      f2 += (long long)(parts->r[r].P / parts->r[r].tm + 2) * parts->r[r].nq;
+    }
+    const int stage = f2 * 8 <= 144 * 1024 ? (int)f2 : 0;                           // staged through LDS when it fits
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_parts_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_parts_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+      attr_set = true;
+    }
+    if (y && P <= 8192 && (C >> 3) <= 256) {      // mid-size images: finalize + apply in one launch
+      if (nchunk > GN_FUSED_MAXCHUNK) { nchunk = GN_FUSED_MAXCHUNK; ppb = cdiv(P, nchunk); nchunk = cdiv(P, ppb); }
+      hipLaunchKernelGGL(gn_parts_kernel<256>, dim3(nchunk, B), dim3(256), (size_t)stage * 8, st, x, y, *parts, gamma, beta, stats, scale, shift,
+                         P, C, G, rpb, ppb, eps, silu, stage);
+      return CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(gn_parts_kernel<1024>, dim3(1, B), dim3(1024), (size_t)stage * 8, st, x, (act_t*)nullptr, *parts, gamma, beta, stats, scale,
+                       shift, P, C, G, rpb, ppb, eps, silu, stage);
+    if (y) hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, scale, shift, y, P, C, rpb, ppb, silu);
+    return CHECK_LAUNCH();
+  }
   static const bool small_ok = getenv("DMX_NO_GN_SMALL") == nullptr, fused_ok = getenv("DMX_NO_GN_FUSED") == nullptr;
   // one workgroup per (group, image) holds its slice in registers: one launch, but its 8-byte pieces of 2C-byte rows are the
   // worst case for the memory pipeline -- it wins only where the tensor is tiny (<= 512 pixels: launch latency rules)

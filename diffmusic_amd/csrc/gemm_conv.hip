@@ -63,7 +63,9 @@ bool glds_ok(const GemmDesc& d) {
 }
 int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   g_last_cfg = cfg;
-  if (d.flags & EPI_LNFOLD) return dmx_gemm_launch_ln(cfg, d, stream);       // (gemm_ln.hip: the same tiles with the row statistics in the K loop)
+  if (d.flags & EPI_LNFOLD) return dmx_gemm_launch_ln(cfg, d, stream);       // (gemm_ln.hip: the same tiles with the LayerNorm correction ahead of the epilogue)
+  if (d.flags & EPI_ROWSTATS) return dmx_gemm_launch_rowstats(cfg, d, stream);   // (... and with the row-statistics epilogue)
+  if (d.flags & EPI_GNSTATS) return dmx_gemm_launch_gnstats(cfg, d, stream);     // (gemm_gn.hip: GroupNorm partial sums of the stored tile)
   switch (cfg) {
     case 1: return launch_glds<256, 256, 2, 4, 2>(d, stream);
     case 2: return launch_glds<256, 128, 4, 2, 3>(d, stream);
@@ -258,7 +260,7 @@ __global__ void splitk_epilogue_kernel(const GemmDesc p, const float* __restrict
 int splitk_plan(const GemmDesc& d, int* tile) {
   static const bool off = getenv("DMX_NO_SPLITK") != nullptr;
   if (off || !g_splitk_ws || d.Z != 1 || !glds_ok(d)) return 1;
-  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_GEGLU | EPI_LNFOLD)) return 1;
+  if (d.flags & (EPI_ACCUM | EPI_F32OUT | EPI_TANH | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_GEGLU | EPI_LNFOLD | EPI_ROWSTATS)) return 1;
   if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return 1;
   if ((d.N & 7) || (d.ldc & 3)) return 1;
   const int nk = (d.K + BK - 1) / BK;
@@ -346,10 +348,33 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
     if ((d.flags & EPI_MASKBITS) && (!d.XB || d.ldxb * 8 < d.N)) return DMX_ERR_SHAPE;
     if ((d.flags & EPI_BITS2) && (!d.B2 || d.ldb2 * 8 < d.N)) return DMX_ERR_SHAPE;
   }
+  if ((d.flags & EPI_LNFOLD) && (d.flags & EPI_BIAS)) {
+    // with a folded LayerNorm the bias (d.bias, folded: b + W beta) is added together with the LayerNorm correction ahead of the epilogue
+    GemmDesc q = d;
+    q.flags &= ~EPI_BIAS;
+    return dmx_gemm_launch(q, stream);
+  }
   if (d.flags & EPI_LNFOLD) {
-    // LayerNorm fold: single-tap projection over the whole normalised width, statistics need every wave to see all of K
-    if (d.ntaps != 1 || d.K != d.Ci || !d.colsum || d.Z != 1 || (d.flags & (EPI_F32OUT | EPI_MASK | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_ACCUM | EPI_TANH | EPI_LRELU2)))
+    // LayerNorm fold: single-tap projection over the whole normalised width, row statistics from the producer of A
+    if (d.ntaps != 1 || d.K != d.Ci || !d.colsum || !d.rowstats_in || d.nslots < 1 || d.Z != 1 ||
+        (d.flags & (EPI_F32OUT | EPI_MASK | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_ACCUM | EPI_TANH | EPI_LRELU2 | EPI_ROWSTATS)))
       return DMX_ERR_SHAPE;
+  }
+  if (d.flags & EPI_ROWSTATS) {
+    // row statistics: 16-bit output through the LDS-staged epilogue, identity row map, whole 32-column slots
+    if (!d.rowstats_out || d.nslots * 32 != d.N || d.Z != 1 || ((d.ldc | d.ldr) & 7) ||
+        (d.flags & (EPI_F32OUT | EPI_MASK | EPI_MASKBITS | EPI_BITS2 | EPI_SOFTBWD | EPI_ACCUM | EPI_TANH | EPI_LRELU2 | EPI_GEGLU | EPI_NO_C)))
+      return DMX_ERR_SHAPE;
+    if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return DMX_ERR_SHAPE;
+  }
+  dmx_gemm_reset_last_tile_rows();
+  if (d.flags & EPI_GNSTATS) {
+    // GroupNorm partial sums ride on the LDS-staged 16-bit epilogue of an unsplit launch; anything else launches WITHOUT them and reports
+    // 0 tile rows, so that the caller's GroupNorm takes its own statistics pass
+    const bool can = d.gn_part && d.Z == 1 && !(d.flags & (EPI_F32OUT | EPI_NO_C | EPI_GEGLU | EPI_SOFTBWD | EPI_MASKBITS | EPI_BITS2 | EPI_LNFOLD | EPI_ROWSTATS | EPI_LRELU2)) &&
+                     !((d.N | d.ldc | d.ldr | d.ldx | d.ldc2) & 7);
+    int kt = 12;
+    if (!can || splitk_plan(d, &kt) > 1) { GemmDesc q = d; q.flags &= ~EPI_GNSTATS; return dmx_gemm_launch(q, stream); }
   }
   int ktile = 12;
   const int ksp = splitk_plan(d, &ktile);

@@ -121,6 +121,9 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   constexpr bool BITS = EM == 1;          // sign-bit tape paths
   constexpr bool SOFT = EM == 2;          // fused softmax backward (EPI_SOFTBWD)
   constexpr bool GEGLU = EM == 3;         // value * gelu(gate) of interleaved fragment pairs, half-width output (EPI_GEGLU)
+  constexpr bool ROWS = EM == 4;          // per-row partial sums of the output for a LayerNorm folded into the consumer (EPI_ROWSTATS)
+  static_assert(!ROWS || FN == 2 || FN == 4, "row statistics come in slots of 32 columns");
+  constexpr bool GNS = EM == 5;           // GroupNorm partial sums of the output tile for the consumer's GroupNorm (EPI_GNSTATS)
   static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs accumulator fragments");
   constexpr int CH = EpiChunk<FM>::CH;
   constexpr int IB = EpiChunk<FM>::IB;
@@ -148,8 +151,17 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     const int n = n0 + j * 16 + lq * 4;
     bcol[j] = ((flags & EPI_BIAS) && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // (static_for, not a pragma-unrolled loop: with five 32-row chunks (FM = 10) the compiler gave up on unrolling once the body
-  //  grew, indexed the accumulators dynamically and demoted all 160 of them to scratch)
+  // EPI_GNSTATS: (sum v, sum v^2) of the STORED 16-bit values per 4-channel quad over the rows of this wave tile, split at the image
+  // boundary when the tile straddles two images (rows per image = HqWq).  A lane of the row-major phase owns 8 channels = 2 quads of
+  // RPI-strided rows: gs[0..3] = (s, q) of its two quads for the first image, gs[4..7] for the second.  Reduced over the lanes of a
+  // column chunk after the last chunk and written to slot (image, wave tile index inside the image); gn_parts_kernel (elementwise.hip)
+  // Chan-combines the slots.  Taken from the LDS-staged tile stage_out leaves behind (like emit_bits): the values GroupNorm will read,
+  // no accumulator registers held longer.
+  float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int GN_TM = FM * 16;
+  const int gn_b0 = GNS ? m0 / HqWq : 0;
+  const int gn_bnd = (gn_b0 + 1) * HqWq;                       // first GEMM row of the next image
+  const bool gn_straddle = gn_bnd < m0 + GN_TM && gn_bnd < mend;
   static_for<0, FM / IB>([&](auto H) {
     constexpr int h = decltype(H)::value;
     // ---- output row of each tile row this lane touches in the row-major phases
@@ -233,6 +245,26 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     // EPI_BITS2: a separate sweep over the packed tile stage_out left in LDS -- one byte per 16-byte chunk, bit e <=> channel ncol + e > 0,
     // the backward sweep's leaky-relu' mask.  (Taking the bytes from the registers of the store loop instead was measured in round 3:
     // no gain forward, 5-8 % slower C = 32 backward instances through register allocation; scripts/dev/pair_bench.py.)
+    auto emit_gn = [&]() {
+#ifndef DMX_BF16
+      typedef _Float16 dmx_h2 __attribute__((ext_vector_type(2)));
+      const dmx_h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const uint4 v = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
+        if (orows[it] >= 0 && col_ok) {
+          const dmx_h2 a0 = __builtin_bit_cast(dmx_h2, v.x), a1 = __builtin_bit_cast(dmx_h2, v.y);
+          const dmx_h2 a2 = __builtin_bit_cast(dmx_h2, v.z), a3 = __builtin_bit_cast(dmx_h2, v.w);
+          const float s0 = __builtin_amdgcn_fdot2(a0, one, __builtin_amdgcn_fdot2(a1, one, 0.f, false), false);
+          const float q0 = __builtin_amdgcn_fdot2(a0, a0, __builtin_amdgcn_fdot2(a1, a1, 0.f, false), false);
+          const float s1 = __builtin_amdgcn_fdot2(a2, one, __builtin_amdgcn_fdot2(a3, one, 0.f, false), false);
+          const float q1 = __builtin_amdgcn_fdot2(a2, a2, __builtin_amdgcn_fdot2(a3, a3, 0.f, false), false);
+          if (gn_straddle && m0 + h * CH + it * RPI + rr >= gn_bnd) { gs[4] += s0; gs[5] += q0; gs[6] += s1; gs[7] += q1; }
+          else { gs[0] += s0; gs[1] += q0; gs[2] += s1; gs[3] += q1; }
+        }
+      }
+#endif
+    };
     auto emit_bits = [&]() {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
@@ -378,10 +410,41 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
 #pragma unroll
         for (int j = 0; j < FN; ++j) { f32x4& a = acc[h * IB + ii][j]; a[0] = tanhf(a[0]); a[1] = tanhf(a[1]); a[2] = tanhf(a[2]); a[3] = tanhf(a[3]); }
     }
+    if constexpr (ROWS) {
+      // EPI_ROWSTATS: (sum v, sum v^2) of every output row over each 32-column slot of this wave's columns, from the final fp32 values
+      // (what the LayerNorm folded into the next projection needs; ln_apply in gemm_tile.h adds the slots of a row).  A lane holds 4
+      // values per fragment of row 16 ii + lr: two fragments make a slot, two xor-shuffles over lq finish it, lane lq == 0 stores it.
+      if (flags & EPI_ROWSTATS) {
+        float2* rso = reinterpret_cast<float2*>(p.rowstats_out);
+        const int ns = p.nslots;
+#pragma unroll
+        for (int ii = 0; ii < IB; ++ii) {
+          const int m = m0 + h * CH + ii * 16 + lr;
+#pragma unroll
+          for (int sl = 0; sl < FN / 2; ++sl) {
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+              const int j = sl * 2 + jj;
+              const f32x4& a = acc[h * IB + ii][j];
+              if (n0 + j * 16 + lq * 4 < p.N) {
+                sv += (a[0] + a[1]) + (a[2] + a[3]);
+                qv += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+              }
+            }
+            sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+            qv += __shfl_xor(qv, 16, 64); qv += __shfl_xor(qv, 32, 64);
+            const int slot = (n0 >> 5) + sl;
+            if (lq == 0 && m < mend && slot < ns) rso[(long long)m * ns + slot] = make_float2(sv, qv);
+          }
+        }
+      }
+    }
     const bool bits2 = (flags & EPI_BITS2) != 0;
     if (!(flags & EPI_NO_C)) {
       stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
       if constexpr (BITS) { if (bits2 && !(flags & EPI_LRELU2)) emit_bits(); }
+      if constexpr (GNS) { if (flags & EPI_GNSTATS) emit_gn(); }
       DMX_LDS_SYNC();
     }
     if (flags & EPI_LRELU2) {
@@ -394,6 +457,24 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       DMX_LDS_SYNC();
     }
   });
+  if constexpr (GNS) {
+    if ((flags & EPI_GNSTATS) && m0 < mend) {
+#pragma unroll
+      for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
+      }
+      if (rr == 0 && col_ok) {
+        const int nq = p.N >> 2, slots = (HqWq + GN_TM - 1) / GN_TM + 1, kt = m0 / GN_TM;
+        float* dst = p.gn_part + (((long long)gn_b0 * slots + (kt - (gn_b0 * HqWq) / GN_TM)) * nq + (ncol >> 2)) * 2;
+        *reinterpret_cast<float4*>(dst) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+        if (gn_straddle) {       // the same tile is slot 0 of the next image
+          float* dh = p.gn_part + (((long long)(gn_b0 + 1) * slots) * nq + (ncol >> 2)) * 2;
+          *reinterpret_cast<float4*>(dh) = make_float4(gs[4], gs[5], gs[6], gs[7]);
+        }
+      }
+    }
+  }
 #undef DMX_LDS_SYNC
 }
 

@@ -17,50 +17,70 @@ constexpr int DMX_DEF_BIG = 0;
 
 // ---- LayerNorm folded into the projection that consumes it (EPI_LNFOLD; the U-Net's LN -> QKV / Q / FF1 pairs).
 //   LN(x) . W^T + b  =  rstd * (x . W'^T - mean * colsum) + b',   W' = W diag(gamma),  colsum[n] = sum_k W'[n, k],  b' = b + W beta
-// The GEMM runs on the RAW rows; mean / rstd of a row come from the activation fragments the wave feeds to its MFMAs anyway: lane
-// (lr, lq) holds 8 values of row 16 i + lr per fragment, every wave sees all K of its rows, so a lane's partial sums plus two
-// xor-shuffles over lq give the row statistics in exactly the lanes that hold the row's accumulators.  No normalised tensor, no
-// LayerNorm launch; sums in fp32 of exact fp16 products (v_dot2_f32_f16), E[x^2] - mean^2 like layernorm_kernel.
-__device__ __forceinline__ void ln_acc(const frag8_t& a, float& s, float& q) {
-#ifndef DMX_BF16
-  typedef _Float16 dmx_h2 __attribute__((ext_vector_type(2)));
-  const dmx_h2 one = {(_Float16)1.0f, (_Float16)1.0f};
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const dmx_h2 v = {a[2 * p], a[2 * p + 1]};
-    s = __builtin_amdgcn_fdot2(v, one, s, false);
-    q = __builtin_amdgcn_fdot2(v, v, q, false);
-  }
-#else
-#pragma unroll
-  for (int p = 0; p < 8; ++p) { const float f = (float)a[p]; s += f; q += f * f; }
-#endif
-}
-template <int FM, int FN>
-__device__ __forceinline__ void ln_apply(const GemmDesc& p, f32x4 (&acc)[FM][FN], float (&ln_s)[FM], float (&ln_q)[FM], int n0, int lq) {
+// The GEMM runs on the RAW rows with the stock K loop; mean / rstd of a row come from per-row partial sums (sum x, sum x^2 per 32
+// columns) that the GEMM which PRODUCED the rows wrote from its epilogue (EPI_ROWSTATS, gemm_epilogue.h).  Lane (lr, lq) owns the
+// accumulators of rows 16 i + lr: the four lq lanes of a row split its slots and two xor-shuffles complete the sums in exactly the lanes
+// that need them.  No normalised tensor, no LayerNorm launch, nothing added to the K loop.
+// (Round 4 first gathered the statistics from the activation fragments inside the K loop with v_dot2c_f32_f16: the 8-wave tiles lost the
+//  5-6 us per launch that the removed layernorm kernels had cost, and the FN = 2 tiles produced wrong accumulators in lanes 48-63 on
+//  full grids -- VALU beside the hand-scheduled asm fragment reads; scripts/dev/r04_lnfold_debug.py.)
+// prologue part (all threads of the workgroup; runs while the first tiles are in flight, when registers are free): (mean, rstd) of the BM
+// rows of the tile and the BN row sums of the packed weights go to LDS -- s_ln[BM] float2, s_cs[BN] float.  After the K loop ln_apply
+// needs two short LDS reads per row fragment instead of global round trips with 128+ accumulators live (fetched there, the statistics
+// cost the 256 x 256 tile 7 us per launch -- more than the layernorm launch they replace; profiles/r04_unet_lnfold.log).
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void ln_prologue(const GemmDesc& p, int m0, int n0, float2* s_ln, float* s_cs) {
+  // TPR adjacent lanes share a row and split its slots; each issues up to 8 loads back to back (one memory round trip for the usual
+  // <= 32 slots: a one-load-at-a-time loop over 20 slots cost the small tiles 4-5 us of exposed latency per launch)
+  constexpr int TPR = NT / BM >= 4 ? 4 : (NT / BM >= 2 ? 2 : 1);
+  const int tid = threadIdx.x, ns = p.nslots;
+  const int r = tid / TPR, sub = tid - r * TPR;
   const float inv_c = 1.f / (float)p.K;
-  float4 cs[FN];
+  if (r < BM) {                                   // (whole TPR-lane groups take the branch together: the shuffles below stay inside a group)
+    const int m = m0 + r;
+    const bool row_ok = m < p.M;
+    const float2* rs = reinterpret_cast<const float2*>(p.rowstats_in) + (long long)(row_ok ? m : 0) * ns;
+    float si = 0.f, qi = 0.f;
+    for (int t0 = 0; t0 < ns; t0 += TPR * 8) {
+      float2 v[8];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int n = n0 + j * 16 + lq * 4;
-    cs[j] = n < p.N ? *reinterpret_cast<const float4*>(p.colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u * TPR + sub;
+        v[u] = (row_ok && t < ns) ? rs[t] : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { si += v[u].x; qi += v[u].y; }
+    }
+    if constexpr (TPR >= 2) { si += __shfl_xor(si, 1, 64); qi += __shfl_xor(qi, 1, 64); }
+    if constexpr (TPR >= 4) { si += __shfl_xor(si, 2, 64); qi += __shfl_xor(qi, 2, 64); }
+    const float mean = si * inv_c;
+    if (sub == 0) s_ln[r] = make_float2(mean, rsqrtf(fmaxf(qi * inv_c - mean * mean, 0.f) + p.ln_eps));
   }
+  // row sums of the packed weights and the folded bias (b + W beta; added here rather than by the epilogue's EPI_BIAS path, which costs a
+  // large tile ~2 us): s_cs[0 .. BN) and s_cs[BN .. 2 BN)
+  for (int c = tid; c < BN; c += NT) {
+    const bool ok = n0 + c < p.N;
+    s_cs[c] = ok ? p.colsum[n0 + c] : 0.f;
+    s_cs[BN + c] = (ok && p.bias) ? p.bias[n0 + c] : 0.f;
+  }
+}
+// after the K loop: rows 16 i + lr of the wave (tile row r0), columns 16 j + 4 lq .. + 3 (tile column c0)
+template <int FM, int FN, int BN>
+__device__ __forceinline__ void ln_apply(f32x4 (&acc)[FM][FN], const float2* s_ln, const float* s_cs, int r0, int c0, int lr, int lq) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    float s = ln_s[i], q = ln_q[i];
-    s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-    q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-    const float mean = s * inv_c;
-    const float rstd = rsqrtf(fmaxf(q * inv_c - mean * mean, 0.f) + p.ln_eps);
+  for (int j = 0; j < FN; ++j) {            // (column fragment outermost: 8 live registers of column data instead of 8 FN)
+    const float4 cs = *reinterpret_cast<const float4*>(s_cs + c0 + j * 16 + lq * 4);
+    const float4 bs = *reinterpret_cast<const float4*>(s_cs + BN + c0 + j * 16 + lq * 4);
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
+    for (int i = 0; i < FM; ++i) {
+      const float2 st = s_ln[r0 + i * 16 + lr];
+      const float mean = st.x, rstd = st.y;
       f32x4& a = acc[i][j];
-      a[0] = rstd * (a[0] - mean * cs[j].x); a[1] = rstd * (a[1] - mean * cs[j].y);
-      a[2] = rstd * (a[2] - mean * cs[j].z); a[3] = rstd * (a[3] - mean * cs[j].w);
+      a[0] = __builtin_fmaf(rstd, a[0] - mean * cs.x, bs.x); a[1] = __builtin_fmaf(rstd, a[1] - mean * cs.y, bs.y);
+      a[2] = __builtin_fmaf(rstd, a[2] - mean * cs.z, bs.z); a[3] = __builtin_fmaf(rstd, a[3] - mean * cs.w, bs.w);
     }
   }
 }
-
 
 template <int BM, int BN, int WM, int WN, int EM, bool LNF = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
@@ -85,6 +105,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   const long long coff = zo * p.sCo + zi * p.sCi;
 
   if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
+  float2* s_ln = reinterpret_cast<float2*>(smem + 2 * STAGE + DMX_MAX_TAPS * 4);      // LNF: (mean, rstd) of the BM rows, then BN weight row sums
+  float* s_cs = reinterpret_cast<float*>(smem + 2 * STAGE + DMX_MAX_TAPS * 4 + BM * 8);
+  if constexpr (LNF) ln_prologue<BM, BN, NT>(p, tm * BM, tn * BN, s_ln, s_cs);
 
   // ---- per-thread gather bookkeeping (rows are fixed over the K loop)
   const int cc = tid & 7, r0 = tid >> 3;
@@ -162,9 +185,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ln_s[FM], ln_q[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) ln_s[i] = ln_q[i] = 0.f;
 
   const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
@@ -189,15 +209,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j)
           acc[i][j] = DMX_MFMA16(wf[j], af[i], acc[i][j]);
-      if constexpr (LNF) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) ln_acc(af[i], ln_s[i], ln_q[i]);
-      }
     }
     if (ks + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
   }
-  if constexpr (LNF) ln_apply<FM, FN>(p, acc, ln_s, ln_q, tn * BN + wn * TN, lq);
+  if constexpr (LNF) ln_apply<FM, FN, BN>(acc, s_ln, s_cs, wm * TM, wn * TN, lr, lq);
 
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
@@ -376,9 +392,6 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float ln_s[LNF ? FM : 1], ln_q[LNF ? FM : 1];        // EPI_LNFOLD: per-lane partial sums of x and x^2 of rows 16 i + lr
-#pragma unroll
-  for (int i = 0; i < (LNF ? FM : 1); ++i) ln_s[i] = ln_q[i] = 0.f;
 
   // NSTAGE-deep ring: tiles ks+1 .. ks+NSTAGE-1 are in flight while tile ks is consumed.  Every iteration issues
   // exactly one stage (past the end the offsets are out of range -> zero fill, no memory traffic), so the vmcnt
@@ -386,6 +399,9 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int nk = ks1 > ks0 ? ks1 - ks0 : 0;
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s) issue(s, s);
+  float2* s_ln = reinterpret_cast<float2*>(smem + NSTAGE * STAGE);                   // LNF: behind the ring (launch_glds_t sizes it)
+  float* s_cs = reinterpret_cast<float*>(smem + NSTAGE * STAGE + BM * 8);
+  if constexpr (LNF) ln_prologue<BM, BN, NW * 64>(p, m0, tn * BN, s_ln, s_cs);       // (under the latency of the ring's first tiles)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
   __builtin_amdgcn_s_barrier();
   DMX_GSTAMP(1);
@@ -418,12 +434,11 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   auto kloop = [&](auto LAGT) {
     constexpr bool LAG = decltype(LAGT)::value;
     int cur = 0, nxt = NSTAGE - 1;
-    auto mfma_step = [&wf0, &wf1, &af, &acc, &ln_s, &ln_q](auto ST) {
+    auto mfma_step = [&wf0, &wf1, &af, &acc](auto ST) {
       constexpr int st = decltype(ST)::value;
       constexpr int kk = st / FM, i = st - kk * FM;
 #pragma unroll
       for (int j = 0; j < FN; ++j) acc[i][j] = DMX_MFMA16(kk ? wf1[j] : wf0[j], af[st], acc[i][j]);
-      if constexpr (LNF) ln_acc(af[st], ln_s[i], ln_q[i]);          // row statistics from the fragment the MFMAs just consumed
       __builtin_amdgcn_sched_barrier(0);
     };
     for (int ks = 0; ks < nk; ++ks) {
@@ -528,7 +543,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // drain the zero-fill tail ...
   __builtin_amdgcn_s_barrier();                          // ... of every wave before the stage buffers are reused by the epilogue
   DMX_GSTAMP(2);
-  if constexpr (LNF) ln_apply<FM, FN>(p, acc, ln_s, ln_q, tn * BN + wn * TN, lq);
+  if constexpr (LNF) ln_apply<FM, FN, BN>(acc, s_ln, s_cs, wm * TM, wn * TN, lr, lq);
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
     gemm_epilogue<FM, FN>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EM, bool LNF = false>
 int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int SMEM = NSTAGE * (BM + BN) * 128;       // (the tap table of this kernel lives in a register, not in LDS)
+  constexpr int SMEM = NSTAGE * (BM + BN) * 128 + (LNF ? BM * 8 + BN * 8 : 0);       // (the tap table of this kernel lives in a register, not in LDS)
   static_assert(SMEM <= 160 * 1024, "tile ring exceeds the 160 KiB of LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -589,7 +604,7 @@ int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
 template <int BM, int BN, int WM, int WN, int EM, bool LNF = false>
 int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
   constexpr int NT = WM * WN * 64;
-  constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4;
+  constexpr int SMEM = 2 * (BM + BN) * 128 + DMX_MAX_TAPS * 4 + (LNF ? BM * 8 + BN * 8 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, WM, WN, EM, LNF>),

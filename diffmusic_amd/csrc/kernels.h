@@ -6,8 +6,17 @@
 
 // ---- elementwise.hip
 size_t dmx_gn_scratch_floats(int B, int C, int G);
+// partial sums of a GroupNorm input left by its producers (EPI_GNSTATS): see gn_parts_kernel (elementwise.hip)
+struct GnRegion {
+  float* part = nullptr;        // [image][slot][nq][2] fp32
+  int tm = 0, P = 0, nq = 0;    // rows per slot; GEMM rows per image of the producing launch; quads per slot row (producer N / 4)
+  int qoff = 0, cq = 0;         // first quad of this source in the normalised tensor; real quads of this source (C / 4)
+};
+struct GnParts { int n = 0; GnRegion r[8]; };
+size_t dmx_gn_part_floats(int B, int P, int N);                      // fp32 elements of one region's buffer (worst case: 32-row slots)
 int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, float* stats, float* scale,
-                      float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st);
+                      float* shift, float* partial, int B, int P, int C, int G, float eps, int silu, hipStream_t st,
+                      const GnParts* parts = nullptr);
 int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* dx, const float* stats,
                       const float* scale, const float* shift, float* k0, float* k1, float* partial, int B, int P, int C,
                       int G, int silu, hipStream_t st);

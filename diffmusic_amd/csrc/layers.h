@@ -88,6 +88,10 @@ struct Epi {
   int ldrb = 0;                 // row stride of rowbias (0 = the layer's padded Cout)
   const unsigned char* XB = nullptr;   // EPI_MASKBITS source (sign bits, N / 8 bytes per output row)
   unsigned char* B2 = nullptr;         // EPI_BITS2 destination
+  float* rowstats_out = nullptr;       // EPI_ROWSTATS: per-row partial sums of the output (for a LayerNorm folded into the next projection)
+  const float* rowstats_in = nullptr;  // linear_fwd of a LayerNorm-folded layer: the partial sums its input's producer wrote
+  int nslots = 0;                      // 32-column slots per row of either
+  float* gn_part = nullptr;            // EPI_GNSTATS: GroupNorm partial sums of the output (ask dmx_gemm_last_tile_rows() after the launch)
 };
 
 // registry helpers
@@ -110,7 +114,10 @@ int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, i
 // conv3x3(pad 1)(nearest_upsample_x2(in)) without the upsampled tensor: in (B, Hi, Wi, Cip) -> out (B, 2Hi, 2Wi, Cop), and its dgrad
 // dout (B, 2Hi, 2Wi, Cop) -> din (B, Hi, Wi, Cip) (the gradient w.r.t. the LOW-resolution input, upsample backward included)
 int pack_layer_up2x(ParamStore& ps, ConvLayer& L, hipStream_t st);
-int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
+// gn_buf / gn_tm (optional, 4 entries): GroupNorm partial-sum buffers of the four output-parity launches (EPI_GNSTATS) and, on return, the
+// slot rows each launch used (0 = that launch carried no statistics)
+int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st,
+                  float* const* gn_buf = nullptr, int* gn_tm = nullptr);
 int conv_up2x_bwd(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 int conv_bwd_2d(const ConvLayer& L, const act_t* dout, void* din, int B, int Hi, int Wi, const Epi& e, hipStream_t st);
 // plain (batched) NT GEMM: C[z] = alpha * A[z] (M,K; lda) * Bm[z]^T (N,K; ldb)  (+ epilogue)

@@ -285,6 +285,9 @@ static void init_desc(GemmDesc& d, const Epi& e) {
   d.flags = e.flags;
   d.R = e.R; d.X = e.X; d.C2 = e.C2; d.rowbias = e.rowbias; d.ldrb = e.ldrb;
   d.XB = e.XB; d.B2 = e.B2;
+  d.rowstats_out = e.rowstats_out; d.rowstats_in = e.rowstats_in; d.nslots = e.nslots;
+  d.gn_part = e.gn_part;
+  if (e.gn_part) d.flags |= EPI_GNSTATS;
 }
 static void set_out(GemmDesc& d, void* C, int Ho, int Wo, int ldc) {
   d.C = C; d.Ho = Ho; d.Wo = Wo; d.ldc = d.ldr = d.ldx = d.ldc2 = ldc;
@@ -386,12 +389,15 @@ int conv_fwd_2d(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, i
   return dmx_gemm_launch(d, st);
 }
 
-int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st) {
+int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi, int Wi, const Epi& e, hipStream_t st,
+                  float* const* gn_buf, int* gn_tm) {
   if (L.wup.size() != 4) { dmx_set_error("layer has no upsample-folded weights"); return DMX_ERR_STATE; }
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       GemmDesc d;
-      init_desc(d, e);
+      Epi ep = e;
+      if (gn_buf) ep.gn_part = gn_buf[py * 2 + px];
+      init_desc(d, ep);
       if (L.has_bias) { d.bias = L.bias; d.flags |= EPI_BIAS; }
       d.A = in; d.Hi = Hi; d.Wi = Wi; d.Ci = L.Cip; d.lda = L.Cip;
       d.W = L.wup[py * 2 + px]; d.ntaps = 4; d.K = 4 * L.Cip; d.ldw = d.K;
@@ -405,6 +411,7 @@ int conv_up2x_fwd(const ConvLayer& L, const act_t* in, void* out, int B, int Hi,
         }
       const int rc = dmx_gemm_launch(d, st);
       if (rc != DMX_OK) return rc;
+      if (gn_tm) gn_tm[py * 2 + px] = dmx_gemm_last_tile_rows();
     }
   return DMX_OK;
 }
@@ -467,7 +474,11 @@ int linear_fwd(const ConvLayer& L, const act_t* in, int lda, void* out, int ldc,
   d.N = L.Cop; d.Hq = 1; d.Wq = (int)rows; d.M = (int)rows;
   set_out(d, out, 1, (int)rows, ldc);
   if (L.geglu) d.flags |= EPI_GEGLU;          // out is (rows, Cop / 2): value * gelu(gate), applied in the epilogue
-  if (L.colsum) { d.flags |= EPI_LNFOLD; d.colsum = L.colsum; d.ln_eps = L.ln_eps; }     // `in` holds the RAW rows: LayerNorm happens inside
+  if (L.colsum) {            // `in` holds the RAW rows: LayerNorm happens inside, from the row statistics the producer of `in` wrote
+    if (!e.rowstats_in || e.nslots * 32 != L.Cip) { dmx_set_error("LayerNorm-folded layer needs the row statistics of its input"); return DMX_ERR_STATE; }
+    d.flags |= EPI_LNFOLD; d.colsum = L.colsum; d.ln_eps = L.ln_eps;
+    d.flags &= ~EPI_BIAS;          // the folded bias (d.bias stays set) is added together with the LayerNorm correction, not by the epilogue
+  }
   return dmx_gemm_launch(d, st);
 }
 int linear_bwd(const ConvLayer& L, const act_t* dout, int lda, void* din, int ldc, long long rows, const Epi& e, hipStream_t st) {

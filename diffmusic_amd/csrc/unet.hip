@@ -64,33 +64,37 @@ struct AttnLayer {
   // hres += to_out(attn(l, ctx)) ; l (B,N,C) normalised input, ctx (B,Nc,Cc) or nullptr (self)
   // kv_pre / ldkv: this layer's [k | v] slice (2C columns, row stride ldkv) of a projection of the context computed once per forward
   // for all cross-attention layers (UNet::ctxkv); nullptr: project here
+  // rs / ns: row statistics of `l` when the projections carry a folded LayerNorm (l is then the RAW hidden state); the out-projection
+  // writes the statistics of the updated hidden state back into the same buffer (for the next folded LayerNorm)
   int fwd(Ctx& cx, const act_t* l, const act_t* ctx, int Nc, act_t* hres, int B, int N, const float* colbias,
-          const act_t* kv_pre = nullptr, int ldkv = 0) const {
+          const act_t* kv_pre = nullptr, int ldkv = 0, float* rs = nullptr, int ns = 0) const {
     Arena& A = *cx.arena;
     const size_t mk = A.mark();
     const act_t* kv_in = ctx ? ctx : l;
     const int Nk = ctx ? Nc : N;
     act_t* o = A.bf((size_t)B * N * C);
     Epi e;
+    Epi eq; eq.rowstats_in = rs; eq.nslots = ns;          // projections of the (LayerNorm-folded) hidden state
     if (ctx && ldkv > 0) {
       act_t* q = A.bf((size_t)B * N * C);
-      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
+      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, eq, cx.st));
       CTRY(attention_core(cx, q, kv_pre, kv_pre + C, o, B, N, Nk, C, heads, nullptr, colbias, C, ldkv, ldkv));
     } else if (!ctx && fused) {
       // self-attention: q | k | v come out of one GEMM (N = 3C) and are consumed as strided slices
       act_t* qkv = A.bf((size_t)B * N * 3 * C);
-      CRUN(linear_fwd(to_qkv, l, to_q.Cip, qkv, 3 * C, (long long)B * N, e, cx.st));
+      CRUN(linear_fwd(to_qkv, l, to_q.Cip, qkv, 3 * C, (long long)B * N, eq, cx.st));
       CTRY(attention_core(cx, qkv, qkv + C, qkv + 2 * C, o, B, N, N, C, heads, nullptr, colbias, 3 * C, 3 * C, 3 * C));
     } else {
       act_t* q = A.bf((size_t)B * N * C);
       act_t* k = A.bf((size_t)B * Nk * C);
       act_t* v = A.bf((size_t)B * Nk * C);
-      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, e, cx.st));
-      CRUN(linear_fwd(to_k, kv_in, to_k.Cip, k, C, (long long)B * Nk, e, cx.st));
-      CRUN(linear_fwd(to_v, kv_in, to_v.Cip, v, C, (long long)B * Nk, e, cx.st));
+      CRUN(linear_fwd(to_q, l, to_q.Cip, q, C, (long long)B * N, eq, cx.st));
+      CRUN(linear_fwd(to_k, kv_in, to_k.Cip, k, C, (long long)B * Nk, ctx ? e : eq, cx.st));
+      CRUN(linear_fwd(to_v, kv_in, to_v.Cip, v, C, (long long)B * Nk, ctx ? e : eq, cx.st));
       CTRY(attention_core(cx, q, k, v, o, B, N, Nk, C, heads, nullptr, colbias));
     }
     Epi er; er.flags = EPI_RESID; er.R = hres;
+    if (rs) { er.flags |= EPI_ROWSTATS; er.rowstats_out = rs; er.nslots = ns; }
     CRUN(linear_fwd(to_out, o, C, hres, C, (long long)B * N, er, cx.st));
     A.release(mk);
     return DMX_OK;
@@ -120,7 +124,7 @@ struct Transformer2D {
     proj_out = make_conv2d(ps, pre + ".proj_out", ch, ch, 1, 1, 0, false);
     // LayerNorm folded into the projections that consume it (EPI_LNFOLD): norm1 -> attn1 q/k/v, norm2 -> attn2 q (and k/v when attn2 is
     // self-attention), norm3 -> ff1.  The three layernorm launches and their normalised tensors disappear.
-    ln_fold = getenv("DMX_NO_LN_FOLD") == nullptr && (ch % 8) == 0;
+    ln_fold = getenv("DMX_NO_LN_FOLD") == nullptr && (ch % 32) == 0;      // (row statistics travel in slots of 32 channels)
     if (ln_fold) {
       auto fold = [](ConvLayer& L, const LnParams& ln) { L.ln_g_id = ln.g_id; L.ln_b_id = ln.b_id; L.ln_eps = 1e-5f; };
       fold(attn1.to_q, ln1); fold(attn1.to_k, ln1); fold(attn1.to_v, ln1);
@@ -138,8 +142,10 @@ struct Transformer2D {
     return DMX_OK;
   }
   // x (B,H,W,C) -> out (B,H,W,C); out may not alias x
+  // x_parts / out_parts: GroupNorm partial sums of x (from its producer) and for `out` (Resnet2D::fwd's protocol, blocks.h)
   int fwd(Ctx& cx, const act_t* x, act_t* out, int B, int H, int W, const act_t* ctx = nullptr, int Nc = 0,
-          const float* colbias = nullptr, const act_t* kv_pre = nullptr, int ldkv = 0) const {
+          const float* colbias = nullptr, const act_t* kv_pre = nullptr, int ldkv = 0, const GnParts* x_parts = nullptr,
+          GnParts* out_parts = nullptr) const {
     Arena& A = *cx.arena;
     const int N = H * W;
     const size_t mk = A.mark();
@@ -147,26 +153,35 @@ struct Transformer2D {
     act_t* n = A.bf((size_t)B * N * C);
     act_t* hbuf = A.bf((size_t)B * N * C);
     act_t* l = A.bf((size_t)B * N * C);
-    CTRY(norm.fwd(cx, x, n, B, N, 0, gt));
+    CTRY(norm.fwd(cx, x, n, B, N, 0, gt, x_parts));
     Epi e;
-    CRUN(conv_fwd_2d(proj_in, n, hbuf, B, H, W, e, cx.st));
+    // ln_fold: every GEMM that writes the hidden state also writes its per-row partial sums (EPI_ROWSTATS) -- the statistics of the
+    // LayerNorm folded into the projection that reads it next
+    const int ns = C / 32;
+    float* rs = ln_fold ? A.f32((size_t)B * N * ns * 2) : nullptr;
+    {
+      Epi ei;
+      if (ln_fold) { ei.flags = EPI_ROWSTATS; ei.rowstats_out = rs; ei.nslots = ns; }
+      CRUN(conv_fwd_2d(proj_in, n, hbuf, B, H, W, ei, cx.st));
+    }
     // (ln_fold: the projections read the raw hidden state `hbuf` and normalise inside; they finish before the out-projection's
     //  residual epilogue rewrites hbuf -- launches of one stream run in order)
     const act_t* lin = ln_fold ? hbuf : l;
     if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln1.gamma, ln1.beta, B * N, C, 1e-5f, cx.st));
-    CTRY(attn1.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr));
+    CTRY(attn1.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr, nullptr, 0, rs, ns));
     if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln2.gamma, ln2.beta, B * N, C, 1e-5f, cx.st));
-    if (cross > 0) CTRY(attn2.fwd(cx, lin, ctx, Nc, hbuf, B, N, colbias, kv_pre, ldkv));
-    else CTRY(attn2.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr));   // encoder_hidden_states=None -> self-attention
+    if (cross > 0) CTRY(attn2.fwd(cx, lin, ctx, Nc, hbuf, B, N, colbias, kv_pre, ldkv, rs, ns));
+    else CTRY(attn2.fwd(cx, lin, nullptr, 0, hbuf, B, N, nullptr, nullptr, 0, rs, ns));   // encoder_hidden_states=None -> self-attention
     if (!ln_fold) CRUN(dmx_layernorm_fwd(hbuf, l, ln3.gamma, ln3.beta, B * N, C, 1e-5f, cx.st));
     {
       const size_t mk2 = A.mark();
       act_t* gg = A.bf((size_t)B * N * C * 4);
+      Epi ef; ef.rowstats_in = rs; ef.nslots = ns;
       if (ff1.geglu) {
-        CRUN(linear_fwd(ff1, lin, C, gg, C * 4, (long long)B * N, e, cx.st));       // [values | gates] -> values * gelu(gates) in the epilogue
+        CRUN(linear_fwd(ff1, lin, C, gg, C * 4, (long long)B * N, ef, cx.st));       // [values | gates] -> values * gelu(gates) in the epilogue
       } else {
         act_t* f = A.bf((size_t)B * N * C * 8);
-        CRUN(linear_fwd(ff1, lin, C, f, C * 8, (long long)B * N, e, cx.st));
+        CRUN(linear_fwd(ff1, lin, C, f, C * 8, (long long)B * N, ef, cx.st));
         CRUN(dmx_geglu(f, gg, (long long)B * N, C * 4, cx.st));
       }
       Epi er; er.flags = EPI_RESID; er.R = hbuf;
@@ -174,7 +189,9 @@ struct Transformer2D {
       A.release(mk2);
     }
     Epi eo; eo.flags = EPI_RESID; eo.R = x;
+    eo.gn_part = out_parts ? gn_parts_buf(*out_parts) : nullptr;
     CRUN(conv_fwd_2d(proj_out, hbuf, out, B, H, W, eo, cx.st));
+    if (eo.gn_part) gn_parts_push(cx, out_parts, eo.gn_part, cx.dry ? 0 : dmx_gemm_last_tile_rows(), N, proj_out.Cop, C);
     A.release(mk);
     return DMX_OK;
   }
@@ -375,14 +392,20 @@ struct UNet : Model {
     return DMX_OK;
   }
 
-  struct Skip { act_t* p; int H, W, C; };
+  struct Skip { act_t* p; int H, W, C; GnParts gp; };
 
   // runs the napl transformers of one layer in sequence: in -> out (both (B,H,W,ch)); tmp is a scratch of the same size
-  int run_attn(Ctx& cx, const Transformer2D* tf, const act_t* in, act_t* out, act_t* tmp, int B, int H, int W) {
+  // in_parts: GroupNorm partial sums of `in`; out_parts: for `out` (the last transformer's proj_out fills it)
+  int run_attn(Ctx& cx, const Transformer2D* tf, const act_t* in, act_t* out, act_t* tmp, int B, int H, int W,
+               const GnParts* in_parts = nullptr, GnParts* out_parts = nullptr) {
     const act_t* src = in;
     int kctx = 0;
+    GnParts sp = in_parts ? *in_parts : GnParts(), mid[2];
+    if (!in_parts) sp.n = -1;
     for (int q = 0; q < napl; ++q) {
       act_t* dst = ((napl - 1 - q) & 1) ? tmp : out;          // last one lands in `out`
+      GnParts* dp = out_parts;
+      if (q + 1 < napl) { mid[q & 1] = gn_parts_new(cx, B, (size_t)H * W, pad8(tf[q].C)); dp = &mid[q & 1]; }
       const bool cross = tf[q].cross > 0;
       const act_t* kvp = nullptr;
       int ldkv = 0;
@@ -390,9 +413,11 @@ struct UNet : Model {
         const int off = ctxkv_slot(kctx, &tf[q].attn2);
         if (off >= 0) { kvp = ctx_kv[kctx] + off; ldkv = ctxkv[kctx].total; }
       }
-      CTRY(tf[q].fwd(cx, src, dst, B, H, W, cross ? ctx_ptr[kctx] : nullptr, cross ? ctx_n[kctx] : 0, cross ? ctx_bias[kctx] : nullptr, kvp, ldkv));
+      CTRY(tf[q].fwd(cx, src, dst, B, H, W, cross ? ctx_ptr[kctx] : nullptr, cross ? ctx_n[kctx] : 0, cross ? ctx_bias[kctx] : nullptr, kvp, ldkv,
+                     &sp, dp));
       if (cross) ++kctx;
       src = dst;
+      if (dp) sp = *dp; else sp.n = -1;
     }
     return DMX_OK;
   }
@@ -460,36 +485,46 @@ struct UNet : Model {
     std::vector<Skip> skips;
     const int Cin_p = conv_in.Cip;
     act_t* cur = A.bf((size_t)B * H * W * boc[0]);
+    // curp: GroupNorm partial sums of `cur`, written by the launch that produced it (EPI_GNSTATS, blocks.h): the two-launch GroupNorm of
+    // the full- and half-resolution levels loses its statistics pass; skips carry theirs to the up path
+    GnParts curp = gn_parts_new(cx, B, (size_t)H * W, pad8(boc[0]));
     {
       const size_t mk = A.mark();
       act_t* x16 = A.bf((size_t)B * H * W * Cin_p);
       CRUN(dmx_nchw_f32_to_nhwc_bf16(x, x16, B, cfg.in_channels, H * W, Cin_p, 1.f, st));
-      CRUN(conv_fwd_2d(conv_in, x16, cur, B, H, W, e, st));
+      Epi ei; ei.gn_part = gn_parts_buf(curp);
+      CRUN(conv_fwd_2d(conv_in, x16, cur, B, H, W, ei, st));
+      if (ei.gn_part) gn_parts_push(cx, &curp, ei.gn_part, dry ? 0 : dmx_gemm_last_tile_rows(), H * W, conv_in.Cop, boc[0]);
       A.release(mk);
     }
-    skips.push_back({cur, H, W, boc[0]});
+    skips.push_back({cur, H, W, boc[0], curp});
     // ---- down
     for (int i = 0; i < nb; ++i) {
       Block& b = down[i];
       for (size_t j = 0; j < b.res.size(); ++j) {
         act_t* y = A.bf((size_t)B * H * W * b.ch);
+        GnParts yp = gn_parts_new(cx, B, (size_t)H * W, pad8(b.ch));
         if (b.has_attn) {
           act_t* y2 = A.bf((size_t)B * H * W * b.ch);   // resnet output (transient but simpler to keep)
           act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * b.ch) : nullptr;
-          CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
-          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
+          GnParts y2p = gn_parts_new(cx, B, (size_t)H * W, pad8(b.ch));
+          CTRY(b.res[j].fwd(cx, cur, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total, &curp, &y2p));
+          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W, &y2p, &yp));
         } else {
-          CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
+          CTRY(b.res[j].fwd(cx, cur, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total, &curp, &yp));
         }
-        cur = y;
-        skips.push_back({cur, H, W, b.ch});
+        cur = y; curp = yp;
+        skips.push_back({cur, H, W, b.ch, curp});
       }
       if (b.has_sampler) {
         const int H2 = (H + 2 - 3) / 2 + 1, W2 = (W + 2 - 3) / 2 + 1;
         act_t* y = A.bf((size_t)B * H2 * W2 * b.ch);
-        CRUN(conv_fwd_2d(b.sampler, cur, y, B, H, W, e, st));
-        cur = y; H = H2; W = W2;
-        skips.push_back({cur, H, W, b.ch});
+        GnParts yp = gn_parts_new(cx, B, (size_t)H2 * W2, b.sampler.Cop);
+        Epi es; es.gn_part = gn_parts_buf(yp);
+        CRUN(conv_fwd_2d(b.sampler, cur, y, B, H, W, es, st));
+        if (es.gn_part) gn_parts_push(cx, &yp, es.gn_part, dry ? 0 : dmx_gemm_last_tile_rows(), H2 * W2, b.sampler.Cop, b.ch);
+        cur = y; curp = yp; H = H2; W = W2;
+        skips.push_back({cur, H, W, b.ch, curp});
       }
     }
     // ---- mid
@@ -499,10 +534,12 @@ struct UNet : Model {
       act_t* y1 = A.bf((size_t)B * H * W * cm);
       act_t* y2 = A.bf((size_t)B * H * W * cm);
       act_t* y3 = napl > 1 ? A.bf((size_t)B * H * W * cm) : nullptr;
-      CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr, rb_of(mid_r0), temb_total));
-      CTRY(run_attn(cx, mid_attns.data(), y0, y1, y3, B, H, W));
-      CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr, rb_of(mid_r1), temb_total));
-      cur = y2;
+      GnParts p0 = gn_parts_new(cx, B, (size_t)H * W, pad8(cm)), p1 = gn_parts_new(cx, B, (size_t)H * W, pad8(cm)),
+              p2 = gn_parts_new(cx, B, (size_t)H * W, pad8(cm));
+      CTRY(mid_r0.fwd(cx, cur, y0, B, H, W, semb, nullptr, rb_of(mid_r0), temb_total, &curp, &p0));
+      CTRY(run_attn(cx, mid_attns.data(), y0, y1, y3, B, H, W, &p0, &p1));
+      CTRY(mid_r1.fwd(cx, y1, y2, B, H, W, semb, nullptr, rb_of(mid_r1), temb_total, &p1, &p2));
+      cur = y2; curp = p2;
     }
     // ---- up
     int curC = boc[nb - 1];
@@ -516,33 +553,45 @@ struct UNet : Model {
         act_t* y = A.bf((size_t)B * H * W * b.ch);
         act_t* y2 = b.has_attn ? A.bf((size_t)B * H * W * b.ch) : nullptr;
         act_t* y3 = (b.has_attn && napl > 1) ? A.bf((size_t)B * H * W * b.ch) : nullptr;
+        GnParts yp = gn_parts_new(cx, B, (size_t)H * W, pad8(b.ch)), y2p;
+        if (b.has_attn) y2p = gn_parts_new(cx, B, (size_t)H * W, pad8(b.ch));
         const size_t mk = A.mark();
         act_t* cat = A.bf((size_t)B * H * W * cc);
         CRUN(dmx_concat2(cur, s.p, cat, (long long)B * H * W, curC, s.C, st));               // [hidden | skip] in one launch
+        const GnParts catp = gn_parts_concat(curp, s.gp, curC);      // the partial sums of both sources describe the concatenation
         if (b.has_attn) {
-          CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
-          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W));
+          CTRY(b.res[j].fwd(cx, cat, y2, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total, &catp, &y2p));
+          CTRY(run_attn(cx, &b.attn[j * napl], y2, y, y3, B, H, W, &y2p, &yp));
         } else {
-          CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total));
+          CTRY(b.res[j].fwd(cx, cat, y, B, H, W, semb, nullptr, rb_of(b.res[j]), temb_total, &catp, &yp));
         }
         A.release(mk);
-        cur = y; curC = b.ch;
+        cur = y; curp = yp; curC = b.ch;
       }
       if (b.has_sampler) {
         const Skip nxt = skips.back();                 // upsample to the matching skip's size (forward_upsample_size)
         const int H2 = nxt.H, W2 = nxt.W;
         act_t* y = A.bf((size_t)B * H2 * W2 * b.ch);
+        const bool fold = up2x && H2 == 2 * H && W2 == 2 * W;
+        GnParts upp;
+        float* ubuf[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (gn_parts_wanted((size_t)H2 * W2)) for (int q = 0; q < (fold ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, fold ? (size_t)H * W : (size_t)H2 * W2, b.sampler.Cop);
+        else upp.n = -1;
         const size_t mk = A.mark();
-        if (up2x && H2 == 2 * H && W2 == 2 * W) {
+        if (fold) {
           // exact x2 (the other levels interpolate to the skip tensor's odd size): nearest x2 + conv3x3 as four parity convolutions
-          CRUN(conv_up2x_fwd(b.sampler, cur, y, B, H, W, e, st));
+          int tms[4] = {0, 0, 0, 0};
+          CRUN(conv_up2x_fwd(b.sampler, cur, y, B, H, W, e, st, ubuf[0] ? ubuf : nullptr, tms));
+          if (ubuf[0]) for (int q = 0; q < 4; ++q) gn_parts_push(cx, &upp, ubuf[q], tms[q], H * W, b.sampler.Cop, b.ch);
         } else {
           act_t* u = A.bf((size_t)B * H2 * W2 * b.ch);
           CRUN(dmx_upsample_nearest(cur, u, B, H, W, H2, W2, b.ch, st));
-          CRUN(conv_fwd_2d(b.sampler, u, y, B, H2, W2, e, st));
+          Epi eu; eu.gn_part = ubuf[0];
+          CRUN(conv_fwd_2d(b.sampler, u, y, B, H2, W2, eu, st));
+          if (ubuf[0]) gn_parts_push(cx, &upp, ubuf[0], dry ? 0 : dmx_gemm_last_tile_rows(), H2 * W2, b.sampler.Cop, b.ch);
         }
         A.release(mk);
-        cur = y; H = H2; W = W2;
+        cur = y; curp = upp; H = H2; W = W2;
       }
     }
     // ---- out
@@ -550,7 +599,7 @@ struct UNet : Model {
       GnTape gt = norm_out.alloc(cx, B);
       act_t* n = A.bf((size_t)B * H * W * boc[0]);
       act_t* o = A.bf((size_t)B * H * W * conv_out.Cop);
-      CTRY(norm_out.fwd(cx, cur, n, B, H * W, 1, gt));
+      CTRY(norm_out.fwd(cx, cur, n, B, H * W, 1, gt, &curp));
       CRUN(conv_fwd_2d(conv_out, n, o, B, H, W, e, st));
       CRUN(dmx_nhwc_bf16_to_nchw_f32(o, eps, B, cfg.out_channels, H * W, conv_out.Cop, 1.f, st));
     }

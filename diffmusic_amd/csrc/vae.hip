@@ -96,10 +96,18 @@ struct VaeDecoder : Model {
     CRUN(dmx_nchw_f32_to_nhwc_bf16(z, z16, B, cfg.latent_channels, (int)P, Lp, z_scale, st));
     Epi e0;
     CRUN(conv_fwd_2d(post_quant, z16, a0, B, H, W, e0, st));
-    CRUN(conv_fwd_2d(conv_in, a0, x, B, H, W, e0, st));
+    // xp: GroupNorm partial sums of the current tensor x, written by the launch that produced it (EPI_GNSTATS): every GroupNorm of the
+    // decoder whose input comes straight out of a GEMM epilogue runs without its statistics pass
+    GnParts xp = gn_parts_new(cx, B, P, conv_in.Cop);
+    {
+      Epi ei; ei.gn_part = gn_parts_buf(xp);
+      CRUN(conv_fwd_2d(conv_in, a0, x, B, H, W, ei, st));
+      if (ei.gn_part) gn_parts_push(cx, &xp, ei.gn_part, dry ? 0 : dmx_gemm_last_tile_rows(), (int)P, conv_in.Cop, Cmid);
+    }
     act_t* y = A.bf(B * P * Cmid);
-    CTRY(mid0.fwd(cx, x, y, B, H, W, nullptr, keep ? &t_mid0 : nt));
-    x = y;
+    GnParts yp = gn_parts_new(cx, B, P, pad8(Cmid));
+    CTRY(mid0.fwd(cx, x, y, B, H, W, nullptr, keep ? &t_mid0 : nt, nullptr, 0, &xp, &yp));
+    x = y; xp = yp;
     {  // mid attention (one head of dim Cmid)
       const int N = (int)P, C = Cmid;
       attn_x = x;
@@ -108,47 +116,65 @@ struct VaeDecoder : Model {
       aP = keep ? A.bf((size_t)B * N * pad8(N)) : nullptr;
       ao = keep ? A.bf((size_t)B * N * C) : nullptr;      // O = P V stays on the tape: delta = rowsum(dO * O) in the backward pass
       act_t* out = A.bf((size_t)B * N * C);
+      GnParts op = gn_parts_new(cx, B, P, pad8(C));
       const size_t mk = A.mark();
       act_t* xn = A.bf((size_t)B * N * C);
       act_t* o = keep ? ao : A.bf((size_t)B * N * C);
-      CTRY(attn_gn.fwd(cx, x, xn, B, N, 0, t_attn_gn));
+      CTRY(attn_gn.fwd(cx, x, xn, B, N, 0, t_attn_gn, &xp));
       Epi e;
       CRUN(linear_fwd(to_q, xn, C, aq, C, (long long)B * N, e, st));
       CRUN(linear_fwd(to_k, xn, C, ak, C, (long long)B * N, e, st));
       CRUN(linear_fwd(to_v, xn, C, av, C, (long long)B * N, e, st));
       CTRY(attention_core(cx, aq, ak, av, o, B, N, N, C, 1, aP, nullptr));
       Epi er; er.flags = EPI_RESID; er.R = x;
-      CRUN(linear_fwd(to_out, o, C, out, C, (long long)B * N, er, st));
+      er.gn_part = gn_parts_buf(op);
+      if (er.gn_part) {       // as a 1x1 convolution over the (H, W) image: the same GEMM, with rows-per-image known to the statistics epilogue
+        CRUN(conv_fwd_2d(to_out, o, out, B, H, W, er, st));
+        gn_parts_push(cx, &op, er.gn_part, dry ? 0 : dmx_gemm_last_tile_rows(), (int)P, to_out.Cop, C);
+      } else {
+        CRUN(linear_fwd(to_out, o, C, out, C, (long long)B * N, er, st));
+      }
       A.release(mk);
-      x = out;
+      x = out; xp = op;
     }
     y = A.bf(B * P * Cmid);
-    CTRY(mid1.fwd(cx, x, y, B, H, W, nullptr, keep ? &t_mid1 : nt));
-    x = y;
+    yp = gn_parts_new(cx, B, P, pad8(Cmid));
+    CTRY(mid1.fwd(cx, x, y, B, H, W, nullptr, keep ? &t_mid1 : nt, nullptr, 0, &xp, &yp));
+    x = y; xp = yp;
     for (int i = 0; i < nb; ++i) {
       const int ch = up_ch[i];
       for (int j = 0; j <= cfg.layers_per_block; ++j) {
         y = A.bf(B * P * ch);
-        CTRY(up_res[i][j].fwd(cx, x, y, B, H, W, nullptr, keep ? &t_up[i][j] : nt));
-        x = y;
+        yp = gn_parts_new(cx, B, P, pad8(ch));
+        CTRY(up_res[i][j].fwd(cx, x, y, B, H, W, nullptr, keep ? &t_up[i][j] : nt, nullptr, 0, &xp, &yp));
+        x = y; xp = yp;
       }
       if (i != nb - 1) {
         const int H2 = H * 2, W2 = W * 2;
         const size_t P2 = (size_t)H2 * W2;
         y = A.bf(B * P2 * ch);
+        // partial sums of the upsampler's output: one region per output-parity launch (each covers P low-resolution positions per image)
+        GnParts up;
+        float* ubuf[4] = {nullptr, nullptr, nullptr, nullptr};
+        if (gn_parts_wanted(P2)) for (int q = 0; q < (up2x ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, up2x ? P : P2, up_conv[i].Cop);
+        else up.n = -1;
         const size_t mk = A.mark();
         Epi e;
         if (up2x) {
           // nearest x2 + conv3x3 as four 2x2-tap convolutions of the low-resolution tensor (one per output parity): 4/9 of the
           // multiply-adds and no upsampled tensor (Upsample2D, diffusers 0.31.0 semantics)
-          CRUN(conv_up2x_fwd(up_conv[i], x, y, B, H, W, e, st));
+          int tms[4] = {0, 0, 0, 0};
+          CRUN(conv_up2x_fwd(up_conv[i], x, y, B, H, W, e, st, ubuf[0] ? ubuf : nullptr, tms));
+          if (ubuf[0]) for (int q = 0; q < 4; ++q) gn_parts_push(cx, &up, ubuf[q], tms[q], (int)P, up_conv[i].Cop, ch);
         } else {
           act_t* u = A.bf(B * P2 * ch);
           CRUN(dmx_upsample_nearest(x, u, B, H, W, H2, W2, ch, st));
+          e.gn_part = ubuf[0];
           CRUN(conv_fwd_2d(up_conv[i], u, y, B, H2, W2, e, st));
+          if (ubuf[0]) gn_parts_push(cx, &up, ubuf[0], dry ? 0 : dmx_gemm_last_tile_rows(), (int)P2, up_conv[i].Cop, ch);
         }
         A.release(mk);
-        x = y; H = H2; W = W2; P = P2;
+        x = y; xp = up; H = H2; W = W2; P = P2;
       }
     }
     final_x = x;
@@ -157,7 +183,7 @@ struct VaeDecoder : Model {
       const size_t mk = A.mark();
       act_t* n = A.bf(B * P * norm_out.g.C);
       float* m8 = A.f32(B * P * 8);
-      CTRY(norm_out.fwd(cx, x, n, B, (int)P, 1, t_norm_out));
+      CTRY(norm_out.fwd(cx, x, n, B, (int)P, 1, t_norm_out, &xp));
       Epi e; e.flags = EPI_F32OUT;
       CRUN(conv_fwd_2d(conv_out, n, m8, B, H, W, e, st));
       if (mel_f32) CRUN(dmx_gather_col_f32(m8, mel_f32, (long long)B * P, 8, 0, st));

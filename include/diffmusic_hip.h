@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD: colsum, ln_eps) */
+#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD / EPI_ROWSTATS / EPI_GNSTATS: colsum, ln_eps, rowstats_in, rowstats_out, nslots, gn_part) */
 #define DMX_MAX_STAGES 8
 
 typedef struct dmx_model dmx_model; /* opaque network handle (weights repacked for MFMA) */
@@ -229,6 +229,14 @@ int dmx_conv_pair_group_raw(int n, const void* descs_a, const void* descs_b, siz
 size_t dmx_groupnorm_scratch_floats(int B, int C, int G);
 int dmx_groupnorm_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
                       float* partial, int B, int P, int C, int G, float eps, int silu, void* stream);
+/* GroupNorm whose statistics come from partial sums the PRODUCERS of x wrote in their GEMM epilogues (GemmDesc flag EPI_GNSTATS,
+ * gn_part): nreg (1..8) regions, part[i] = buffer of dmx_groupnorm_part_floats(B, P_i, N_i) floats, geom[6 i ..] = {rows per slot (what
+ * dmx_gemm_last_tile_rows_raw() reported after the producing launch), GEMM rows per image of that launch, N_i / 4, first 4-channel
+ * quad of the source in x, real quads of the source, 0}.  Same outputs as dmx_groupnorm_raw; no statistics pass over x. */
+size_t dmx_groupnorm_part_floats(int B, int P, int N);
+int dmx_groupnorm_parts_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
+                            int B, int P, int C, int G, float eps, int silu, int nreg, float* const* part, const int* geom, void* stream);
+int dmx_gemm_last_tile_rows_raw(void);
 
 #ifdef __cplusplus
 }

@@ -430,13 +430,21 @@ def test_sign_bit_tape_forward_and_backward(B, T, Cc, k, dil):
     assert torch.equal(res["full"], res["bits"])
 
 
+def _row_slots(v):
+    """(sum, sum of squares) per 32-column slot of every row: the EPI_ROWSTATS layout [row][slot][2]"""
+    M, C = v.shape
+    v = v.float().reshape(M, C // 32, 32)
+    return torch.stack([v.sum(-1), (v * v).sum(-1)], dim=-1).contiguous()
+
+
 @pytest.mark.parametrize("cfg", [0, 1, 2, 10, 11, 12, 13, 14, 18, 3, 4, 6])
-@pytest.mark.parametrize("M,K,N", [(1000, 320, 384), (4032, 384, 1152), (333, 200, 72)])
+@pytest.mark.parametrize("M,K,N", [(1000, 320, 384), (4032, 384, 1152), (333, 224, 72)])
 def test_layernorm_fold_gemm(cfg, M, K, N):
-    """EPI_LNFOLD: out = LayerNorm(x) W^T + b computed by ONE GEMM on the raw rows -- row statistics gathered from the activation
-    fragments in the K loop, gamma folded into the packed weights, beta into the bias, and the accumulators corrected with the
-    packed row sums (csrc/gemm_tile.h ln_acc / ln_apply; the U-Net's LN -> QKV / FF1 pairs).  Every instantiated tile, K with a
-    partial last 64-channel group, M / N tails; rows with a large common offset (mean >> std) stress the mean * colsum cancellation."""
+    """EPI_LNFOLD: out = LayerNorm(x) W^T + b computed by ONE GEMM on the raw rows -- gamma folded into the packed weights, beta into the
+    bias, the accumulators corrected with the packed row sums and the rows' mean / rstd taken from the 32-column partial sums their
+    producer wrote (csrc/gemm_tile.h ln_apply; the U-Net's LN -> QKV / FF1 pairs).  Every instantiated tile, full grids (several
+    workgroups per CU), K with a partial last 64-channel group, M / N tails; rows with a large common offset (mean >> std) stress the
+    mean * colsum cancellation."""
     from diffmusic_amd import _lib as L
     g = torch.Generator().manual_seed(100 + cfg)
     x = (torch.randn(M, K, generator=g) * (0.2 + torch.rand(M, 1, generator=g)) + 3.0 * torch.randn(M, 1, generator=g)).to(_adt())
@@ -448,13 +456,52 @@ def test_layernorm_fold_gemm(cfg, M, K, N):
     colsum = wf.float().sum(1).contiguous()
     bf = (bias + w @ beta).contiguous()
     out = torch.empty(M, N, dtype=_adt(), device="cuda")
-    xd, wd, rd, cd, bd = x.cuda(), wf.cuda(), res.cuda(), colsum.cuda(), bf.cuda()
-    d = _desc(L, A=xd, W=wd, C=out, bias=bd, R=rd, colsum=cd, ln_eps=1e-5, M=M, N=N, K=K, ldw=K, Hi=1, Wi=M, Ci=K, lda=K, Hq=1, Wq=M,
-              ntaps=1, Ho=1, Wo=M, ldc=N, ldr=N, ldx=N, ldc2=N, flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_LNFOLD, tdy=[0], tdx=[0], tile_cfg=cfg)
+    xd, wd, rd, cd, bd, sd = x.cuda(), wf.cuda(), res.cuda(), colsum.cuda(), bf.cuda(), _row_slots(x).cuda()
+    d = _desc(L, A=xd, W=wd, C=out, bias=bd, R=rd, colsum=cd, ln_eps=1e-5, rowstats_in=sd, nslots=K // 32, M=M, N=N, K=K, ldw=K, Hi=1, Wi=M,
+              Ci=K, lda=K, Hq=1, Wq=M, ntaps=1, Ho=1, Wo=M, ldc=N, ldr=N, ldx=N, ldc2=N, flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_LNFOLD,
+              tdy=[0], tdx=[0], tile_cfg=cfg)
     _run(L, d)
     ref = F.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ w.t() + bias + res.float()
     err = _rel(out.cpu(), ref)
     assert err < 4e-3, err
-    # a split-K plan cannot carry the fold (every wave must see all of K): the forced plan is refused, not silently mis-normalised
+    # a split-K plan cannot carry the fold: the forced plan is refused, not silently mis-normalised
     d.tile_cfg = 212
     assert L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 10, 11, 12, 13, 14, 18, 3, 4, 6])
+@pytest.mark.parametrize("M,K,N", [(1000, 320, 384), (4032, 384, 640), (333, 200, 96)])
+def test_rowstats_epilogue(cfg, M, K, N):
+    """EPI_ROWSTATS: the producer of a LayerNorm input writes, next to its 16-bit output, (sum v, sum v^2) of every row per 32-column slot
+    from the final fp32 values (bias and residual included) -- csrc/gemm_epilogue.h.  Checked against the sums of the fp32 reference rows
+    and, chained, as the statistics input of an EPI_LNFOLD consumer."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(300 + cfg)
+    x = torch.randn(M, K, generator=g).to(_adt())
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(_adt())
+    bias = torch.randn(N, generator=g)
+    res = (2.0 * torch.randn(M, N, generator=g) + torch.randn(M, 1, generator=g)).to(_adt())
+    out = torch.empty(M, N, dtype=_adt(), device="cuda")
+    st = torch.full((M, N // 32, 2), float("nan"), device="cuda")
+    xd, wd, rd, bd = x.cuda(), w.cuda(), res.cuda(), bias.cuda()
+    d = _desc(L, A=xd, W=wd, C=out, bias=bd, R=rd, rowstats_out=st, nslots=N // 32, M=M, N=N, K=K, ldw=K, Hi=1, Wi=M, Ci=K, lda=K, Hq=1, Wq=M,
+              ntaps=1, Ho=1, Wo=M, ldc=N, ldr=N, ldx=N, ldc2=N, flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_ROWSTATS, tdy=[0], tdx=[0], tile_cfg=cfg)
+    _run(L, d)
+    ref = x.float() @ w.float().t() + bias + res.float()
+    assert _rel(out.cpu(), ref) < 3e-3
+    want = _row_slots(ref)
+    got = st.cpu()
+    assert torch.isfinite(got).all()
+    assert _rel(got[..., 0], want[..., 0]) < 2e-3 and _rel(got[..., 1], want[..., 1]) < 2e-3
+    # chained: LayerNorm over the N columns folded into a second projection that reads the statistics just written
+    N2 = 64
+    w2 = torch.randn(N2, N, generator=g) / N ** 0.5
+    gamma, beta = 0.5 + torch.rand(N, generator=g), 0.3 * torch.randn(N, generator=g)
+    wf = (w2 * gamma).to(_adt())
+    out2 = torch.empty(M, N2, dtype=_adt(), device="cuda")
+    cd, bd2, wfd = wf.float().sum(1).contiguous().cuda(), (w2 @ beta).contiguous().cuda(), wf.cuda()
+    d2 = _desc(L, A=out, W=wfd, C=out2, bias=bd2, colsum=cd, ln_eps=1e-5, rowstats_in=st, nslots=N // 32, M=M, N=N2, K=N, ldw=N, Hi=1, Wi=M,
+               Ci=N, lda=N, Hq=1, Wq=M, ntaps=1, Ho=1, Wo=M, ldc=N2, ldr=N2, ldx=N2, ldc2=N2, flags=L.EPI_BIAS | L.EPI_LNFOLD, tdy=[0], tdx=[0])
+    _run(L, d2)
+    ref2 = F.layer_norm(out.cpu().float(), (N,), gamma, beta, 1e-5) @ w2.t()
+    assert _rel(out2.cpu(), ref2) < 5e-3

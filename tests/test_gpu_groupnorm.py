@@ -53,3 +53,106 @@ def test_groupnorm_forward_plans(B, P, Cc, G, silu):
     sh_ref = beta - mean.repeat_interleave(Cc // G, dim=1) * sc_ref
     assert torch.allclose(scale, sc_ref, atol=1e-6, rtol=3e-5)
     assert torch.allclose(shift, sh_ref, atol=3e-5, rtol=3e-5)
+
+
+def _conv1x1_with_gnstats(L, x, w, bias, res, P, cfg):
+    """(B*P, K) @ w^T + bias + res through dmx_gemm_raw as a 1x1 convolution over images of P pixels, with EPI_GNSTATS.
+    Returns (out fp16 (B*P, N), part buffer, rows per slot)."""
+    M, K = x.shape
+    N = w.shape[0]
+    B = M // P
+    out = torch.empty(M, N, dtype=L.act_dtype(), device="cuda")
+    part = torch.full((L.lib().dmx_groupnorm_part_floats(B, P, N),), float("nan"), device="cuda")
+    d = L.GemmDesc()
+    d.Z = d.Zi = 1
+    d.sy = d.sx = d.osy = d.osx = 1
+    d.alpha = 1.0
+    for k, v in dict(A=x, W=w, C=out, bias=bias, R=res, gn_part=part).items():
+        setattr(d, k, v.data_ptr())
+    for k, v in dict(M=M, N=N, K=K, ldw=K, Hi=1, Wi=P, Ci=K, lda=K, Hq=1, Wq=P, ntaps=1, Ho=1, Wo=P, ldc=N, ldr=N, ldx=N, ldc2=N,
+                     flags=L.EPI_BIAS | L.EPI_RESID | L.EPI_GNSTATS, tile_cfg=cfg).items():
+        setattr(d, k, v)
+    L.check(L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gemm")
+    return out, part, L.lib().dmx_gemm_last_tile_rows_raw()
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 7, 8, 9, 10, 11, 12, 13, 14, 19, 3, 4, 6])
+@pytest.mark.parametrize("B,P,K,Cc,silu", [(3, 1003, 64, 256, 1), (2, 4000, 72, 128, 0), (5, 700, 128, 640, 1)])
+def test_groupnorm_from_producer_partial_sums(cfg, B, P, K, Cc, silu):
+    """EPI_GNSTATS -> gn_parts_kernel: the GEMM that produces a GroupNorm input writes (sum, sum of squares) per wave tile, image and
+    4-channel quad from its epilogue; the GroupNorm combines them (Chan, two sweeps) and normalises WITHOUT a statistics pass.  Every
+    instantiated tile (their wave tiles of 32 ... 160 rows straddle the image boundaries of P = 1003 / 700 at different places),
+    4 / 8 / 20 channels per group, and the classic path on the same tensor as the second reference."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(cfg * 7 + P)
+    G, eps = 32, 1e-5
+    x = torch.randn(B * P, K, generator=g).to(L.act_dtype()).cuda()
+    w = (torch.randn(Cc, K, generator=g) / K ** 0.5).to(L.act_dtype()).cuda()
+    bias = torch.randn(Cc, generator=g).cuda()
+    res = (1.5 * torch.randn(B * P, Cc, generator=g) + 0.7).to(L.act_dtype()).cuda()
+    out, part, tm = _conv1x1_with_gnstats(L, x, w, bias, res, P, cfg)
+    torch.cuda.synchronize()
+    assert tm in (32, 48, 64, 80, 96, 128, 160), tm
+    gamma = (torch.randn(Cc, generator=g) * 0.3 + 1.0).cuda()
+    beta = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    y = torch.empty_like(out)
+    stats, scale, shift = torch.empty(B, G, 2, device="cuda"), torch.empty(B, Cc, device="cuda"), torch.empty(B, Cc, device="cuda")
+    geom = (C.c_int * 6)(tm, P, Cc // 4, 0, Cc // 4, 0)
+    parts = (C.c_void_p * 1)(part.data_ptr())
+    L.check(L.lib().dmx_groupnorm_parts_raw(C.c_void_p(out.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                            C.c_void_p(beta.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(scale.data_ptr()),
+                                            C.c_void_p(shift.data_ptr()), B, P, Cc, G, eps, silu, 1, parts, geom,
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "groupnorm_parts")
+    torch.cuda.synchronize()
+    xf = out.float().reshape(B, P, Cc)
+    ref = F.group_norm(xf.transpose(1, 2), G, gamma, beta, eps).transpose(1, 2)
+    if silu:
+        ref = F.silu(ref)
+    got = y.float().reshape(B, P, Cc)
+    assert ((got - ref).norm() / ref.norm()).item() < 1e-3
+    xg = xf.reshape(B, P, G, Cc // G)
+    mean, rstd = xg.mean(dim=(1, 3)), (xg.var(dim=(1, 3), unbiased=False) + eps).rsqrt()
+    assert torch.allclose(stats[..., 0], mean, atol=3e-5, rtol=1e-5)
+    assert torch.allclose(stats[..., 1], rstd, atol=0, rtol=3e-5)
+
+
+def test_groupnorm_parts_over_a_concatenation_and_parity_regions():
+    """Two sources concatenated along the channels (384 + 256 channels, 20 per group: group 19 straddles the seam) and a source that
+    arrives as four regions (the output-parity launches of an upsample-folded convolution: each region covers a quarter of the pixels)."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    B, P, G, eps = 3, 1000, 32, 1e-5
+    Ca, Cb = 384, 256
+    def produce(Cc, Pq, nimg_rows):
+        x = torch.randn(B * Pq, 64, generator=g).to(L.act_dtype()).cuda()
+        w = (torch.randn(Cc, 64, generator=g) / 8.0).to(L.act_dtype()).cuda()
+        bias = torch.randn(Cc, generator=g).cuda()
+        res = (torch.randn(B * Pq, Cc, generator=g) + 0.3).to(L.act_dtype()).cuda()
+        return _conv1x1_with_gnstats(L, x, w, bias, res, Pq, 0)
+    a, pa, tma = produce(Ca, P, P)
+    # source b: four quarter-resolution launches whose rows interleave into the P pixels of an image (pixel = 4 q + launch)
+    quarters = [produce(Cb, P // 4, P // 4) for _ in range(4)]
+    torch.cuda.synchronize()
+    bfull = torch.stack([q[0].reshape(B, P // 4, Cb) for q in quarters], dim=2).reshape(B, P, Cb)
+    cat = torch.cat([a.reshape(B, P, Ca), bfull], dim=2).contiguous()
+    Cc = Ca + Cb
+    gamma = (torch.randn(Cc, generator=g) * 0.3 + 1.0).cuda()
+    beta = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    y = torch.empty_like(cat)
+    stats, scale, shift = torch.empty(B, G, 2, device="cuda"), torch.empty(B, Cc, device="cuda"), torch.empty(B, Cc, device="cuda")
+    geom = [tma, P, Ca // 4, 0, Ca // 4, 0]
+    ptrs = [pa.data_ptr()]
+    for q in quarters:
+        geom += [q[2], P // 4, Cb // 4, Ca // 4, Cb // 4, 0]
+        ptrs.append(q[1].data_ptr())
+    L.check(L.lib().dmx_groupnorm_parts_raw(C.c_void_p(cat.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                            C.c_void_p(beta.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(scale.data_ptr()),
+                                            C.c_void_p(shift.data_ptr()), B, P, Cc, G, eps, 1, 5, (C.c_void_p * 5)(*ptrs), (C.c_int * 30)(*geom),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), "groupnorm_parts")
+    torch.cuda.synchronize()
+    xf = cat.float()
+    ref = F.silu(F.group_norm(xf.transpose(1, 2), G, gamma, beta, eps).transpose(1, 2))
+    assert ((y.float() - ref).norm() / ref.norm()).item() < 1e-3
+    xg = xf.reshape(B, P, G, Cc // G)
+    assert torch.allclose(stats[..., 0], xg.mean(dim=(1, 3)), atol=3e-5, rtol=1e-5)
+    assert torch.allclose(stats[..., 1], (xg.var(dim=(1, 3), unbiased=False) + eps).rsqrt(), atol=0, rtol=3e-5)

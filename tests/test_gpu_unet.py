@@ -103,3 +103,44 @@ def test_layernorm_fold_matches_oracle_and_unfused_path(cfg_name, monkeypatch):
     assert _rel(out.cpu(), oref) < 1e-2 and _rel(out_plain.cpu(), oref) < 1e-2
     assert _rel(out, out_plain) < 5e-3
     assert not torch.equal(out, out_plain)          # the two engines really take different paths
+
+
+@pytest.mark.parametrize("cfg_name", ["musicldm", "audioldm2"])
+def test_unet_groupnorm_from_producer_partial_sums(cfg_name, monkeypatch):
+    """Levels above 512 pixels (1024 at level 0 here): GroupNorm statistics from the producers' epilogues (EPI_GNSTATS), including the
+    skip concatenations of the up path (two sources, group boundaries across the seam) and the folded x2 upsampler (four parity
+    regions).  Equal to the classic path to 16-bit rounding, both at the oracle's level."""
+    from diffmusic_amd.engine import UNetEngine
+    from oracle.models import UNetMusicLDM
+    # (partial sums travel per 4-channel quad: groups of 4 / 8 channels here, like the production widths 128 ... 640)
+    wide = dict(block_out_channels=[128, 128, 256, 256])
+    cfg = dict(SMALL, **wide) if cfg_name == "musicldm" else dict(A2, **wide)
+    eng = UNetEngine(cfg)
+    sd = eng.synth_state_dict(seed=17)
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    B, h, w = 2, 64, 16
+    x = torch.randn(B, 8, h, w, generator=g)
+    if cfg_name == "musicldm":
+        cls = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1)
+        args = (x.cuda(), torch.full((B,), 501.0), cls.cuda())
+        ref = UNetMusicLDM(**cfg)
+        okw = dict(class_labels=cls)
+    else:
+        c0, c1 = torch.randn(B, 8, 48, generator=g), torch.randn(B, 12, 64, generator=g)
+        args = (x.cuda(), torch.full((B,), 501.0), None, c0.cuda(), c1.cuda(), torch.ones(B, 12).cuda())
+        ref = UNetMusicLDM(**{k: v for k, v in cfg.items() if k != "attn_cross_dims"}, attn_cross_dims=(None, 48, 64))
+        okw = dict(encoder_hidden_states=c0, encoder_hidden_states_1=c1, encoder_attention_mask_1=torch.ones(B, 12))
+    ref.load_state_dict(sd, strict=True)
+    out = eng.forward(*args).clone()
+    monkeypatch.setenv("DMX_NO_GN_PARTS", "1")
+    out_classic = eng.forward(*args).clone()
+    monkeypatch.delenv("DMX_NO_GN_PARTS")
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        oref = ref(x, 501, **okw)[0]
+    print(f"GN parts ({cfg_name}): vs oracle {_rel(out.cpu(), oref):.2e}, classic vs oracle {_rel(out_classic.cpu(), oref):.2e}, "
+          f"parts vs classic {_rel(out, out_classic):.2e}")
+    assert _rel(out.cpu(), oref) < 1e-2 and _rel(out_classic.cpu(), oref) < 1e-2
+    assert _rel(out, out_classic) < 5e-3
+    assert not torch.equal(out, out_classic)

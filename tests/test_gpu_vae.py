@@ -36,3 +36,41 @@ def test_vae_decode_fwd_bwd_vs_oracle(B, h, w):
     assert _rel(mel32.cpu(), mref) < 1e-2
     assert _rel(mel.cpu(), mref) < 1e-2
     assert _rel(dz.cpu(), gref) < 3e-2
+
+
+def test_vae_groupnorm_from_producer_partial_sums(monkeypatch):
+    """A latent large enough for the two- and three-launch GroupNorm plans (768 and 3072 pixels): with EPI_GNSTATS the convolutions
+    that produce a GroupNorm input write its partial sums and the GroupNorm skips its statistics pass (csrc/gemm_epilogue.h,
+    gn_parts_kernel).  Same result as the classic path (DMX_NO_GN_PARTS) to 16-bit rounding, both at the oracle's level, forward and
+    backward (the tape's mean / rstd / scale / shift come from the combined partial sums)."""
+    from diffmusic_amd.engine import VaeDecoderEngine
+    from diffmusic_amd import _lib as L
+    from oracle.models import VaeDecoder
+    cfg = dict(SMALL, block_out_channels=[128, 128, 256])      # (partial sums travel per 4-channel quad: groups of 4 / 8 channels)
+    eng = VaeDecoderEngine(cfg)
+    sd = eng.synth_state_dict(seed=6)
+    eng.load_state_dict(sd)
+    ref = VaeDecoder(**cfg)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(23)
+    B, h, w = 3, 24, 8
+    z = torch.randn(B, 8, h, w, generator=g)
+    dmel = torch.randn(B, 4 * h, 4 * w, generator=g).to(L.act_dtype())
+    zs = 1.0 / SMALL["scaling_factor"]
+    res = {}
+    for tag in ("parts", "classic"):
+        if tag == "classic":
+            monkeypatch.setenv("DMX_NO_GN_PARTS", "1")
+        mel, mel32 = eng.decode_hip(z.cuda(), z_scale=zs, want_f32=True)
+        dz = eng.backward(dmel.cuda(), z_scale=zs)
+        torch.cuda.synchronize()
+        res[tag] = (mel32.clone(), dz.clone())
+    monkeypatch.delenv("DMX_NO_GN_PARTS")
+    zr = z.clone().requires_grad_(True)
+    mref = ref.decode(zs * zr).sample[:, 0]
+    (gref,) = torch.autograd.grad((mref * dmel.float()).sum(), zr)
+    for tag, (m, d) in res.items():
+        print(tag, "rel mel", _rel(m.cpu(), mref), "rel grad", _rel(d.cpu(), gref))
+        assert _rel(m.cpu(), mref) < 1e-2 and _rel(d.cpu(), gref) < 3e-2
+    assert _rel(res["parts"][0], res["classic"][0]) < 3e-3 and _rel(res["parts"][1], res["classic"][1]) < 1e-2
+    assert not torch.equal(res["parts"][0], res["classic"][0])          # two different statistics paths really ran
