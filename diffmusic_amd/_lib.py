@@ -51,12 +51,13 @@ class GemmDesc(C.Structure):
                 ("tdy", C.c_byte * 16), ("tdx", C.c_byte * 16), ("resid_inv_slope", C.c_float), ("tile_cfg", C.c_int), ("ldrb", C.c_int), ("ksplit", C.c_int),
                 ("XB", C.c_void_p), ("B2", C.c_void_p), ("ldxb", C.c_int), ("ldb2", C.c_int),
                 ("colsum", C.c_void_p), ("ln_eps", C.c_float), ("rowstats_in", C.c_void_p), ("rowstats_out", C.c_void_p), ("nslots", C.c_int),
-                ("gn_part", C.c_void_p)]
+                ("gn_part", C.c_void_p), ("gnb_x", C.c_void_p), ("gnb_scale", C.c_void_p), ("gnb_shift", C.c_void_p),
+                ("gnb_ldx", C.c_int), ("gnb_silu", C.c_int), ("gnb_stats", C.c_void_p), ("gnb_cpg", C.c_int)]
 
 
 EPI_BIAS, EPI_ROWBIAS, EPI_RESID, EPI_ACCUM, EPI_MASK, EPI_LRELU2, EPI_TANH, EPI_F32OUT, EPI_NO_C, EPI_RESID_INV, EPI_MASKBITS, EPI_BITS2, EPI_SOFTBWD = \
     1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096
-EPI_GEGLU, EPI_LNFOLD, EPI_ROWSTATS, EPI_GNSTATS = 8192, 16384, 32768, 65536
+EPI_GEGLU, EPI_LNFOLD, EPI_ROWSTATS, EPI_GNSTATS, EPI_GNBWD = 8192, 16384, 32768, 65536, 131072
 
 _SIGS = {
     "dmx_abi_version": (C.c_int, []),
@@ -99,6 +100,7 @@ _SIGS = {
     "dmx_groupnorm_part_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "dmx_groupnorm_parts_raw": (C.c_int, [C.c_void_p] * 7 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmx_gemm_last_tile_rows_raw": (C.c_int, []),
+    "dmx_groupnorm_bwd_raw": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmx_prof_dominant": (C.c_int, [C.POINTER(C.c_double)] * 3),
     "dmx_audio_create": (C.c_void_p, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_audio_destroy": (None, [C.c_void_p]),

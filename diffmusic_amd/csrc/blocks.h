@@ -14,6 +14,7 @@ struct Ctx {           // per-call execution context
   hipStream_t st;
   bool dry;
   float* gn_partial;   // scratch for GroupNorm partial sums (model-owned)
+  bool gn_parts = true; // producers write GroupNorm partial sums from their epilogues (EPI_GNSTATS / EPI_GNBWD); the U-Net switches it off
 };
 #define CRUN(expr) do { if (!cx.dry) { int rc_ = (expr); if (rc_ != DMX_OK) return rc_; } } while (0)
 #define CTRY(expr) do { int rc__ = (expr); if (rc__ != DMX_OK) return rc__; } while (0)
@@ -23,8 +24,8 @@ struct GnTape { float* stats = nullptr; float* scale = nullptr; float* shift = n
 // ---- GroupNorm partial sums written by the producers of a tensor (EPI_GNSTATS; kernels.h GnParts): a tensor that will be normalised
 // travels with a GnParts: n > 0 = valid regions, 0 = none requested, -1 = a producer could not provide them (the GroupNorm then makes its
 // own statistics pass).  Buffers live in the arena next to the tensor they describe.
-inline bool gn_parts_wanted(size_t P) {
-  const bool on = getenv("DMX_NO_GN_PARTS") == nullptr;      // (read per call: tests compare both paths in one process)
+inline bool gn_parts_wanted(const Ctx& cx, size_t P) {
+  const bool on = cx.gn_parts && getenv("DMX_NO_GN_PARTS") == nullptr;      // (read per call: tests compare both paths in one process)
   return on && P > 512;                   // (<= 512 pixels: the single-launch gn_small plan, which needs no partial sums)
 }
 inline float* gn_part_alloc(Ctx& cx, int B, size_t P, int Np) { return cx.arena->f32(dmx_gn_part_floats(B, (int)P, Np)); }
@@ -47,7 +48,7 @@ inline const GnParts* gn_parts_valid(const GnParts* p) { return p && p->n > 0 ? 
 // the consumer's GroupNorm would not use partial sums anyway
 inline GnParts gn_parts_new(Ctx& cx, int B, size_t P, int Np) {
   GnParts g;
-  if (gn_parts_wanted(P)) g.r[0].part = gn_part_alloc(cx, B, P, Np); else g.n = -1;
+  if (gn_parts_wanted(cx, P)) g.r[0].part = gn_part_alloc(cx, B, P, Np); else g.n = -1;
   return g;
 }
 inline float* gn_parts_buf(const GnParts& g) { return g.n == 0 ? g.r[0].part : nullptr; }
@@ -70,11 +71,29 @@ struct GnLayer {
                            gn_parts_valid(parts)));
     return DMX_OK;
   }
-  int bwd(Ctx& cx, const act_t* x, const act_t* dy, const act_t* add, act_t* dx, int B, int P, int silu, const GnTape& t) const {
+  // bparts: backward partial sums written by the dgrad launch that produced dy (bwd_epi below)
+  // arm the Epi of the dgrad launch that produces dy of THIS GroupNorm (input x, tape t): the launch writes the backward partial sums into
+  // a fresh buffer (EPI_GNBWD); call bwd_parts() after the launch.  Returns the buffer (nullptr: the classic statistics pass will run).
+  float* bwd_epi(Ctx& cx, Epi& e, const act_t* x, int B, size_t P, int silu, const GnTape& t) const {
+    if (!gn_parts_wanted(cx, P) || ((g.C / g.G) & 3) || (g.C & 7) || getenv("DMX_NO_GN_BWD_PARTS")) return nullptr;
+    float* buf = gn_part_alloc(cx, B, P, g.C);
+    e.gn_part = buf; e.gnb_x = x; e.gnb_scale = t.scale; e.gnb_shift = t.shift; e.gnb_silu = silu;
+    e.gnb_stats = t.stats; e.gnb_cpg = g.C / g.G;
+    return buf;
+  }
+  GnParts bwd_parts(Ctx& cx, float* buf, size_t P) const {
+    GnParts gp;
+    if (buf) gn_parts_push(cx, &gp, buf, cx.dry ? 0 : dmx_gemm_last_tile_rows(), (int)P, g.C, g.C);
+    else gp.n = -1;
+    return gp;
+  }
+  int bwd(Ctx& cx, const act_t* x, const act_t* dy, const act_t* add, act_t* dx, int B, int P, int silu, const GnTape& t,
+          const GnParts* bparts = nullptr) const {
     const size_t mk = cx.arena->mark();
     float* k0 = cx.arena->f32((size_t)B * g.C);
     float* k1 = cx.arena->f32((size_t)B * g.C);
-    CRUN(dmx_groupnorm_bwd(x, dy, add, dx, t.stats, t.scale, t.shift, k0, k1, cx.gn_partial, B, P, g.C, g.G, silu, cx.st));
+    CRUN(dmx_groupnorm_bwd(x, dy, add, dx, t.stats, t.scale, t.shift, k0, k1, cx.gn_partial, B, P, g.C, g.G, silu, cx.st,
+                           gn_parts_valid(bparts)));
     cx.arena->release(mk);
     return DMX_OK;
   }
@@ -123,7 +142,7 @@ struct Resnet2D {
     CTRY(norm1.fwd(cx, x, n, B, (int)P, 1, t.g1, x_parts));
     Epi e1;
     GnParts h1p;
-    float* h1buf = gn_parts_wanted(P) ? gn_part_alloc(cx, B, P, conv1.Cop) : nullptr;      // conv1 -> norm2
+    float* h1buf = gn_parts_wanted(cx, P) ? gn_part_alloc(cx, B, P, conv1.Cop) : nullptr;      // conv1 -> norm2
     if (has_temb && rb_pre) {
       e1.flags = EPI_ROWBIAS; e1.rowbias = rb_pre; e1.ldrb = ldrb;
     } else if (has_temb) {
@@ -159,16 +178,23 @@ struct Resnet2D {
     act_t* a = A.bf(B * P * Cout);
     act_t* b = A.bf(B * P * (Cin > Cout ? Cin : Cout));
     Epi e;
-    CRUN(conv_bwd_2d(conv2, dout, a, B, H, W, e, cx.st));                 // d n2
-    CTRY(norm2.bwd(cx, t.h1, a, nullptr, b, B, (int)P, 1, t.g2));         // d h1 (in b, Cout channels)
+    // the dgrad launches also write the backward sums of the GroupNorm they feed (EPI_GNBWD): norm2.bwd / norm1.bwd skip their pass over x, dy
+    Epi e2;
+    float* pb2 = norm2.bwd_epi(cx, e2, t.h1, B, P, 1, t.g2);
+    CRUN(conv_bwd_2d(conv2, dout, a, B, H, W, e2, cx.st));                // d n2
+    const GnParts bp2 = norm2.bwd_parts(cx, pb2, P);
+    CTRY(norm2.bwd(cx, t.h1, a, nullptr, b, B, (int)P, 1, t.g2, &bp2));   // d h1 (in b, Cout channels)
     act_t* c = A.bf(B * P * Cin);
-    CRUN(conv_bwd_2d(conv1, b, c, B, H, W, e, cx.st));                    // d n1
+    Epi e1;
+    float* pb1 = norm1.bwd_epi(cx, e1, t.x, B, P, 1, t.g1);
+    CRUN(conv_bwd_2d(conv1, b, c, B, H, W, e1, cx.st));                   // d n1
+    const GnParts bp1 = norm1.bwd_parts(cx, pb1, P);
     const act_t* add = dout;
     if (has_shortcut) {
       CRUN(conv_bwd_2d(shortcut, dout, b, B, H, W, e, cx.st));            // reuse b (Cin channels)
       add = b;
     }
-    CTRY(norm1.bwd(cx, t.x, c, add, dx, B, (int)P, 1, t.g1));
+    CTRY(norm1.bwd(cx, t.x, c, add, dx, B, (int)P, 1, t.g1, &bp1));
     A.release(mk);
     return DMX_OK;
   }

@@ -164,5 +164,21 @@ int dmx_groupnorm_parts_raw(const void* x, void* y, const float* gamma, const fl
   return rc;
 }
 int dmx_gemm_last_tile_rows_raw(void) { return dmx_gemm_last_tile_rows(); }
+// GroupNorm(+SiLU) backward: dx = d/dx of <dy, act(GN(x))> (+ add), with the two per-group sums taken from partial sums the dgrad launch
+// that produced dy wrote (EPI_GNBWD; regions as in dmx_groupnorm_parts_raw) or, with nreg == 0, by the classic pass over x and dy.
+// stats / scale / shift: the forward's tape; k0 / k1: (B, C) fp32 scratch; partial: scratch of dmx_groupnorm_scratch_floats (nreg == 0).
+int dmx_groupnorm_bwd_raw(const void* x, const void* dy, const void* add, void* dx, const float* stats, const float* scale, const float* shift,
+                          float* k0, float* k1, float* partial, int B, int P, int C, int G, int silu, int nreg, float* const* part,
+                          const int* geom, void* stream) {
+  if (nreg < 0 || nreg > 8) { dmx_set_error("groupnorm_bwd: 0..8 regions"); return DMX_ERR_SHAPE; }
+  GnParts gp;
+  for (int i = 0; i < nreg; ++i) {
+    GnRegion r;
+    r.part = part[i]; r.tm = geom[i * 6]; r.P = geom[i * 6 + 1]; r.nq = geom[i * 6 + 2]; r.qoff = geom[i * 6 + 3]; r.cq = geom[i * 6 + 4];
+    gp.r[gp.n++] = r;
+  }
+  return dmx_groupnorm_bwd((const act_t*)x, (const act_t*)dy, (const act_t*)add, (act_t*)dx, stats, scale, shift, k0, k1, partial, B, P, C, G,
+                           silu, ST(stream), nreg ? &gp : nullptr);
+}
 
 }  // extern "C"

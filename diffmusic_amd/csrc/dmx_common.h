@@ -114,6 +114,8 @@ enum {
   EPI_GNSTATS = 65536,  // also write GroupNorm partial sums of the stored output to gn_part: (sum v, sum v^2) per 4-channel quad, per wave tile and
                         // image -- [image][slot][N / 4][2] fp32 with slot = wave-tile index inside the image (rows per tile = the tile's TM,
                         // reported by dmx_gemm_last_tile_rows()); the consumer's GroupNorm needs no statistics pass over the tensor
+  EPI_GNBWD = 131072,   // the output is dy of a GroupNorm(+SiLU): also write the BACKWARD partial sums (sum dxh, sum dxh x per quad, slot layout of
+                        // EPI_GNSTATS) to gn_part, from gnb_x (the GroupNorm's input, row stride gnb_ldx), gnb_scale / gnb_shift ([image][N]) and gnb_stats
   EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
                        // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };
@@ -151,7 +153,13 @@ struct GemmDesc {
   const float* rowstats_in;  // EPI_LNFOLD: per-row partial sums [M][nslots][2] written by the producer of A (EPI_ROWSTATS)
   float* rowstats_out;       // EPI_ROWSTATS destination [rows][nslots][2]
   int nslots;                // 32-column slots per row of rowstats_in / rowstats_out
-  float* gn_part;            // EPI_GNSTATS destination
+  float* gn_part;            // EPI_GNSTATS / EPI_GNBWD destination
+  const act_t* gnb_x;        // EPI_GNBWD: the GroupNorm's saved input (rows indexed like C), row stride gnb_ldx elements
+  const float* gnb_scale;    // EPI_GNBWD: gamma * rstd per (image, channel), row stride N
+  const float* gnb_shift;    // EPI_GNBWD: beta - mean * gamma * rstd
+  int gnb_ldx, gnb_silu;
+  const float* gnb_stats;    // EPI_GNBWD: (mean, rstd) per (image, group)
+  int gnb_cpg;               // EPI_GNBWD: channels per group (a multiple of 4)
 };
 
 int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream);

@@ -545,6 +545,64 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const float* __re
   }
 }
 
+// backward finalize from PRODUCER-written partial sums (EPI_GNBWD, gemm_epilogue.h): per slot and 4-channel quad (sum dxh, sum dxh (x - mean))
+// with dxh = dy act'(z) gamma rstd; per group  c1 = sum dxh / n,  c2 = rstd * sum dxh (x - mean) / n,  then k0 / k1 as above.
+// One workgroup per image; thread t owns group t % G and the slots t / G, t / G + blockDim / G, ... (plain sums: no conditioning issue,
+// every term is a product of O(1) factors); batches of 8 loads in flight per thread.
+__global__ __launch_bounds__(1024) void gn_bwd_parts_finalize_kernel(const GnParts sp, const float* __restrict__ stats,
+                                                                      float* __restrict__ k0, float* __restrict__ k1, int P, int C, int G) {
+  __shared__ float s_red[1024];
+  __shared__ float s_c1[64], s_c2[64];
+  const int b = blockIdx.x, cpg = C / G, tid = threadIdx.x, nth = blockDim.x, nslice = nth / G;
+  const bool act = tid < nslice * G;
+  const int g = tid % G, slice = tid / G;
+  float a1 = 0.f, a2 = 0.f;
+  if (act) {
+    for (int r = 0; r < sp.n; ++r) {
+      const GnRegion& R = sp.r[r];
+      int q0, q1;
+      gn_parts_quads(R, g, cpg, q0, q1);
+      if (q1 <= q0) continue;
+      const int ns = gn_parts_nslots(R, b), slots = (R.P + R.tm - 1) / R.tm + 1, nq = q1 - q0;
+      const float2* src = reinterpret_cast<const float2*>(R.part) + (long long)b * slots * R.nq;
+      const int items = ((ns - slice + nslice - 1) / nslice) * nq;             // (slot, quad) pairs of this thread
+      for (int i0 = 0; i0 < items; i0 += 8) {
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = i0 + u, j = slice + (i / nq) * nslice, q = q0 + i % nq;
+          v[u] = (i < items && j < ns && gn_parts_rows(R, b, j) > 0) ? src[j * R.nq + q] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { a1 += v[u].x; a2 += v[u].y; }
+      }
+    }
+  }
+  auto reduce = [&](float v) -> float {
+    __syncthreads();
+    if (act) s_red[slice * G + g] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (tid < G) for (int k = 0; k < nslice; ++k) t += s_red[k * G + tid];
+    return t;
+  };
+  const float t1 = reduce(a1), t2 = reduce(a2);
+  if (tid < G) {
+    const float n = (float)P * cpg;
+    const float mean = stats[((long long)b * G + tid) * 2], rstd = stats[((long long)b * G + tid) * 2 + 1];
+    s_c1[tid] = t1 / n;
+    s_c2[tid] = rstd * t2 / n;                 // (the producer summed dxh (x - mean))
+    (void)mean;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += nth) {
+    const int gg = c / cpg;
+    const float mean = stats[((long long)b * G + gg) * 2], rstd = stats[((long long)b * G + gg) * 2 + 1];
+    k0[(long long)b * C + c] = -s_c1[gg] + s_c2[gg] * rstd * mean;
+    k1[(long long)b * C + c] = -s_c2[gg] * rstd;
+  }
+}
+
 __global__ void gn_bwd_apply_kernel(const act_t* __restrict__ x, const act_t* __restrict__ dy,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ k0, const float* __restrict__ k1,
@@ -1164,10 +1222,18 @@ int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
 
 int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* dx, const float* stats,
                       const float* scale, const float* shift, float* k0, float* k1, float* partial, int B, int P, int C,
-                      int G, int silu, hipStream_t st) {
+                      int G, int silu, hipStream_t st, const GnParts* parts) {
   if ((C & 7) || C % G || G > 64 || (G & (G - 1)) || C > 2048) return DMX_ERR_SHAPE;
   int nt, rpb, nchunk, ppb;
   gn_geom(P, C, nt, rpb, nchunk, ppb);
+  if (parts && parts->n > 0 && ((C / G) & 3) == 0) {
+    // the dgrad launch that produced dy left the two backward sums per slot and quad (EPI_GNBWD): no pass over x and dy for them
+    for (int r = 0; r < parts->n; ++r) if ((long long)B * parts->r[r].P >= (1ll << 30)) return DMX_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_bwd_parts_finalize_kernel, dim3(B), dim3(1024), 0, st, *parts, stats, k0, k1, P, C, G);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nchunk, B), dim3(nt), 0, st, x, dy, scale, shift, k0, k1, add, dx, P, C,
+                       rpb, ppb, silu);
+    return CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunk, B), dim3(nt), (size_t)rpb * C * 2 * sizeof(float), st, x, dy,
                      scale, shift, stats, partial, P, C, G, rpb, ppb, silu);
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(1024), 0, st, partial, stats, k0, k1, P, C, G, nchunk);

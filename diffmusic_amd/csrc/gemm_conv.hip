@@ -65,7 +65,7 @@ int launch_by_cfg(int cfg, const GemmDesc& d, hipStream_t stream) {
   g_last_cfg = cfg;
   if (d.flags & EPI_LNFOLD) return dmx_gemm_launch_ln(cfg, d, stream);       // (gemm_ln.hip: the same tiles with the LayerNorm correction ahead of the epilogue)
   if (d.flags & EPI_ROWSTATS) return dmx_gemm_launch_rowstats(cfg, d, stream);   // (... and with the row-statistics epilogue)
-  if (d.flags & EPI_GNSTATS) return dmx_gemm_launch_gnstats(cfg, d, stream);     // (gemm_gn.hip: GroupNorm partial sums of the stored tile)
+  if (d.flags & (EPI_GNSTATS | EPI_GNBWD)) return dmx_gemm_launch_gnstats(cfg, d, stream);     // (gemm_gn.hip: GroupNorm partial sums of the stored tile)
   switch (cfg) {
     case 1: return launch_glds<256, 256, 2, 4, 2>(d, stream);
     case 2: return launch_glds<256, 128, 4, 2, 3>(d, stream);
@@ -368,13 +368,14 @@ int dmx_gemm_launch(const GemmDesc& d, hipStream_t stream) {
     if (!(d.osy == 1 && d.osx == 1 && d.ooy == 0 && d.oox == 0 && d.Ho == d.Hq && d.Wo == d.Wq)) return DMX_ERR_SHAPE;
   }
   dmx_gemm_reset_last_tile_rows();
-  if (d.flags & EPI_GNSTATS) {
+  if (d.flags & (EPI_GNSTATS | EPI_GNBWD)) {
     // GroupNorm partial sums ride on the LDS-staged 16-bit epilogue of an unsplit launch; anything else launches WITHOUT them and reports
     // 0 tile rows, so that the caller's GroupNorm takes its own statistics pass
-    const bool can = d.gn_part && d.Z == 1 && !(d.flags & (EPI_F32OUT | EPI_NO_C | EPI_GEGLU | EPI_SOFTBWD | EPI_MASKBITS | EPI_BITS2 | EPI_LNFOLD | EPI_ROWSTATS | EPI_LRELU2)) &&
-                     !((d.N | d.ldc | d.ldr | d.ldx | d.ldc2) & 7);
+    bool can = d.gn_part && d.Z == 1 && !(d.flags & (EPI_F32OUT | EPI_NO_C | EPI_GEGLU | EPI_SOFTBWD | EPI_MASKBITS | EPI_BITS2 | EPI_LNFOLD | EPI_ROWSTATS | EPI_LRELU2)) &&
+               !((d.N | d.ldc | d.ldr | d.ldx | d.ldc2) & 7) && (d.flags & (EPI_GNSTATS | EPI_GNBWD)) != (EPI_GNSTATS | EPI_GNBWD);
+    if (d.flags & EPI_GNBWD) can = can && d.gnb_x && d.gnb_scale && d.gnb_shift && d.gnb_stats && !(d.gnb_ldx & 7) && d.gnb_cpg >= 4 && !(d.gnb_cpg & 3) && d.N % d.gnb_cpg == 0;
     int kt = 12;
-    if (!can || splitk_plan(d, &kt) > 1) { GemmDesc q = d; q.flags &= ~EPI_GNSTATS; return dmx_gemm_launch(q, stream); }
+    if (!can || splitk_plan(d, &kt) > 1) { GemmDesc q = d; q.flags &= ~(EPI_GNSTATS | EPI_GNBWD); return dmx_gemm_launch(q, stream); }
   }
   int ktile = 12;
   const int ksp = splitk_plan(d, &ktile);

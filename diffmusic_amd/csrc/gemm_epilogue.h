@@ -124,6 +124,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   constexpr bool ROWS = EM == 4;          // per-row partial sums of the output for a LayerNorm folded into the consumer (EPI_ROWSTATS)
   static_assert(!ROWS || FN == 2 || FN == 4, "row statistics come in slots of 32 columns");
   constexpr bool GNS = EM == 5;           // GroupNorm partial sums of the output tile for the consumer's GroupNorm (EPI_GNSTATS)
+  constexpr bool GNB = EM == 6;           // GroupNorm BACKWARD partial sums: this launch produces dy of a GroupNorm(+SiLU) (EPI_GNBWD)
   static_assert(!GEGLU || FN % 2 == 0, "GEGLU pairs accumulator fragments");
   constexpr int CH = EpiChunk<FM>::CH;
   constexpr int IB = EpiChunk<FM>::IB;
@@ -159,7 +160,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
   // no accumulator registers held longer.
   float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int GN_TM = FM * 16;
-  const int gn_b0 = GNS ? m0 / HqWq : 0;
+  const int gn_b0 = (GNS || GNB) ? m0 / HqWq : 0;
   const int gn_bnd = (gn_b0 + 1) * HqWq;                       // first GEMM row of the next image
   const bool gn_straddle = gn_bnd < m0 + GN_TM && gn_bnd < mend;
   static_for<0, FM / IB>([&](auto H) {
@@ -264,6 +265,69 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         }
       }
 #endif
+    };
+    // EPI_GNBWD: this launch's output is dy, the gradient w.r.t. the OUTPUT of a GroupNorm (+SiLU) whose input x and per-(image, channel)
+    // scale / shift / mean are on the tape: the two backward sums per group -- sum dxh and sum dxh (x - mean) with dxh = dy silu'(x scale +
+    // shift) scale (gn_partial_kernel<1>'s, with the rstd factor left to the finalize kernel) -- are taken here from the staged tile and the
+    // matching rows of x, per wave tile / image / 4-channel quad like the forward sums: the standalone pass over x and dy disappears.
+    auto emit_gnb = [&]() {
+      const int mfirst = m0 + h * CH, mlast = mfirst + CH - 1;
+      const int b_first = mfirst >= gn_bnd ? gn_b0 + 1 : gn_b0, b_last = (gn_straddle && mlast >= gn_bnd) ? gn_b0 + 1 : gn_b0;
+      for (int bb = b_first; bb <= b_last; ++bb) {            // (two passes only for the chunk that contains an image boundary)
+        float sc[8], sf[8];
+        {
+          const float* scp = p.gnb_scale + (long long)bb * p.N + ncol;
+          const float* sfp = p.gnb_shift + (long long)bb * p.N + ncol;
+          const float4 a0 = col_ok ? *reinterpret_cast<const float4*>(scp) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 a1 = col_ok ? *reinterpret_cast<const float4*>(scp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 c0 = col_ok ? *reinterpret_cast<const float4*>(sfp) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 c1 = col_ok ? *reinterpret_cast<const float4*>(sfp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+          sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+          sf[0] = c0.x; sf[1] = c0.y; sf[2] = c0.z; sf[3] = c0.w; sf[4] = c1.x; sf[5] = c1.y; sf[6] = c1.z; sf[7] = c1.w;
+        }
+        // group mean of each of the lane's two quads (a quad lies inside one group: channels per group % 4 == 0).  The second sum is taken
+        // of dxh (x - mean), like gn_partial_kernel<1>: sum dxh x - mean sum dxh afterwards cancels catastrophically in fp32 when the
+        // group's mean dominates (measured: the VAE input-gradient of a clip moved by 3.5 % between batch compositions)
+        const int ngrp = p.N / p.gnb_cpg;
+        const float mu[2] = {col_ok ? p.gnb_stats[((long long)bb * ngrp + ncol / p.gnb_cpg) * 2] : 0.f,
+                             col_ok ? p.gnb_stats[((long long)bb * ngrp + (ncol + 4) / p.gnb_cpg) * 2] : 0.f};
+        // rows of x in flight per lane: a divisor of NIT, at most 4 (8 spilled on the 256 x 256 and 512 x 128 tiles)
+        constexpr int HB = NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : (NIT % 2 == 0 ? 2 : 1));
+#pragma unroll
+        for (int g0 = 0; g0 < NIT; g0 += HB) {
+          uint4 xv[HB];
+          bool ok[HB];
+#pragma unroll
+          for (int it = 0; it < HB; ++it) {
+            const int m = mfirst + (g0 + it) * RPI + rr;
+            ok[it] = orows[g0 + it] >= 0 && col_ok && ((m >= gn_bnd ? gn_b0 + 1 : gn_b0) == bb);
+            xv[it] = *reinterpret_cast<const uint4*>(p.gnb_x + (ok[it] ? (long long)orows[g0 + it] * p.gnb_ldx + ncol : 0ll));
+          }
+#pragma unroll
+          for (int it = 0; it < HB; ++it) {
+            const uint4 dv = *reinterpret_cast<const uint4*>(wl + ((g0 + it) * RPI + rr) * PITCH + cch * 16);
+            if (ok[it]) {
+              const float xf[8] = {alo(xv[it].x), ahi(xv[it].x), alo(xv[it].y), ahi(xv[it].y), alo(xv[it].z), ahi(xv[it].z), alo(xv[it].w), ahi(xv[it].w)};
+              const float df[8] = {alo(dv.x), ahi(dv.x), alo(dv.y), ahi(dv.y), alo(dv.z), ahi(dv.z), alo(dv.w), ahi(dv.w)};
+              float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                float dz = df[e];
+                if (p.gnb_silu) {
+                  const float z = __builtin_fmaf(xf[e], sc[e], sf[e]);
+                  const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-z));
+                  dz *= sg * (1.f + z * (1.f - sg));
+                }
+                const float dxh = dz * sc[e];
+                a1[e >> 2] += dxh;
+                a2[e >> 2] = __builtin_fmaf(dxh, xf[e] - mu[e >> 2], a2[e >> 2]);
+              }
+              if (bb != gn_b0) { gs[4] += a1[0]; gs[5] += a2[0]; gs[6] += a1[1]; gs[7] += a2[1]; }
+              else { gs[0] += a1[0]; gs[1] += a2[0]; gs[2] += a1[1]; gs[3] += a2[1]; }
+            }
+          }
+        }
+      }
     };
     auto emit_bits = [&]() {
 #pragma unroll
@@ -445,6 +509,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       stage_out(reinterpret_cast<act_t*>(p.C), p.ldc, [&](const f32x4& a, float (&o)[4]) { o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; });
       if constexpr (BITS) { if (bits2 && !(flags & EPI_LRELU2)) emit_bits(); }
       if constexpr (GNS) { if (flags & EPI_GNSTATS) emit_gn(); }
+      if constexpr (GNB) { if (flags & EPI_GNBWD) emit_gnb(); }
       DMX_LDS_SYNC();
     }
     if (flags & EPI_LRELU2) {
@@ -457,8 +522,8 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       DMX_LDS_SYNC();
     }
   });
-  if constexpr (GNS) {
-    if ((flags & EPI_GNSTATS) && m0 < mend) {
+  if constexpr (GNS || GNB) {
+    if ((flags & (EPI_GNSTATS | EPI_GNBWD)) && m0 < mend) {
 #pragma unroll
       for (int o = CPR; o < 64; o <<= 1) {
 #pragma unroll

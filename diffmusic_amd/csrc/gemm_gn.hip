@@ -10,19 +10,21 @@ thread_local int g_last_tm = 0;
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int gn_glds(const GemmDesc& d, hipStream_t stream) {
   if ((long long)d.Hq * d.Wq < BM / WM) {            // images smaller than a wave tile: slots could not tell the images apart -- no statistics
-    GemmDesc q = d; q.flags &= ~EPI_GNSTATS;
+    GemmDesc q = d; q.flags &= ~(EPI_GNSTATS | EPI_GNBWD);
     return launch_glds_t<BM, BN, WM, WN, NSTAGE, 0, false>(q, stream);
   }
   g_last_tm = BM / WM;
+  if (d.flags & EPI_GNBWD) return launch_glds_t<BM, BN, WM, WN, NSTAGE, 6, false>(d, stream);
   return launch_glds_t<BM, BN, WM, WN, NSTAGE, 5, false>(d, stream);
 }
 template <int BM, int BN, int WM, int WN>
 int gn_cfg(const GemmDesc& d, hipStream_t stream) {
   if ((long long)d.Hq * d.Wq < BM / WM) {
-    GemmDesc q = d; q.flags &= ~EPI_GNSTATS;
+    GemmDesc q = d; q.flags &= ~(EPI_GNSTATS | EPI_GNBWD);
     return launch_cfg_t<BM, BN, WM, WN, 0, false>(q, stream);
   }
   g_last_tm = BM / WM;
+  if (d.flags & EPI_GNBWD) return launch_cfg_t<BM, BN, WM, WN, 6, false>(d, stream);
   return launch_cfg_t<BM, BN, WM, WN, 5, false>(d, stream);
 }
 }  // namespace
@@ -34,7 +36,8 @@ int dmx_gemm_launch_gnstats(int cfg, const GemmDesc& d, hipStream_t stream) {
   switch (cfg) {
     case 1: return gn_glds<256, 256, 2, 4, 2>(d, stream);
     case 2: return gn_glds<256, 128, 4, 2, 3>(d, stream);
-    case 7: return gn_glds<320, 256, 2, 4, 2>(d, stream);
+    case 7: return (d.flags & EPI_GNBWD) ? gn_glds<256, 256, 2, 4, 2>(d, stream)      // (the backward sums do not fit the 320-row tile's registers)
+                                         : gn_glds<320, 256, 2, 4, 2>(d, stream);
     case 8: return gn_glds<192, 256, 2, 4, 2>(d, stream);
     case 9: return gn_glds<320, 128, 4, 2, 2>(d, stream);
     case 10: return gn_glds<192, 128, 4, 2, 3>(d, stream);

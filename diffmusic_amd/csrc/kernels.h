@@ -19,7 +19,7 @@ int dmx_groupnorm_fwd(const act_t* x, act_t* y, const float* gamma, const float*
                       const GnParts* parts = nullptr);
 int dmx_groupnorm_bwd(const act_t* x, const act_t* dy, const act_t* add, act_t* dx, const float* stats,
                       const float* scale, const float* shift, float* k0, float* k1, float* partial, int B, int P, int C,
-                      int G, int silu, hipStream_t st);
+                      int G, int silu, hipStream_t st, const GnParts* parts = nullptr);
 int dmx_layernorm_fwd(const act_t* x, act_t* y, const float* gamma, const float* beta, int rows, int C, float eps,
                       hipStream_t st);
 int dmx_softmax_fwd(const float* S, act_t* P, const float* colbias, long long rows, int N, long long lds, long long ldp,

@@ -92,6 +92,12 @@ struct Epi {
   const float* rowstats_in = nullptr;  // linear_fwd of a LayerNorm-folded layer: the partial sums its input's producer wrote
   int nslots = 0;                      // 32-column slots per row of either
   float* gn_part = nullptr;            // EPI_GNSTATS: GroupNorm partial sums of the output (ask dmx_gemm_last_tile_rows() after the launch)
+  // EPI_GNBWD (with gn_part): the output is dy of a GroupNorm(+SiLU) with saved input gnb_x and tape scale / shift: backward partial sums
+  const act_t* gnb_x = nullptr;
+  const float* gnb_scale = nullptr;
+  const float* gnb_shift = nullptr;
+  int gnb_silu = 0, gnb_cpg = 0;
+  const float* gnb_stats = nullptr;
 };
 
 // registry helpers

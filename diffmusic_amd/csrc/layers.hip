@@ -287,11 +287,14 @@ static void init_desc(GemmDesc& d, const Epi& e) {
   d.XB = e.XB; d.B2 = e.B2;
   d.rowstats_out = e.rowstats_out; d.rowstats_in = e.rowstats_in; d.nslots = e.nslots;
   d.gn_part = e.gn_part;
-  if (e.gn_part) d.flags |= EPI_GNSTATS;
+  if (e.gn_part) d.flags |= e.gnb_x ? EPI_GNBWD : EPI_GNSTATS;
+  d.gnb_x = e.gnb_x; d.gnb_scale = e.gnb_scale; d.gnb_shift = e.gnb_shift; d.gnb_silu = e.gnb_silu;
+  d.gnb_stats = e.gnb_stats; d.gnb_cpg = e.gnb_cpg;
 }
 static void set_out(GemmDesc& d, void* C, int Ho, int Wo, int ldc) {
   d.C = C; d.Ho = Ho; d.Wo = Wo; d.ldc = d.ldr = d.ldx = d.ldc2 = ldc;
   d.ldxb = d.ldb2 = ldc >> 3;
+  d.gnb_ldx = ldc;
 }
 
 int conv_out_len(const ConvLayer& L, int Ti) {

@@ -487,6 +487,11 @@ struct UNet : Model {
     act_t* cur = A.bf((size_t)B * H * W * boc[0]);
     // curp: GroupNorm partial sums of `cur`, written by the launch that produced it (EPI_GNSTATS, blocks.h): the two-launch GroupNorm of
     // the full- and half-resolution levels loses its statistics pass; skips carry theirs to the up path
+    // OFF by default in the U-Net (DMX_UNET_GN_PARTS=1 switches it on): a slot's position inside the batch decides where an image
+    // boundary cuts it, so two IDENTICAL images of a batch get statistics that differ in the last bits, a few 16-bit activations round
+    // the other way and the cond / uncond rows of a CFG batch with equal conditioning no longer cancel exactly -- guidance_scale times
+    // that jitter (7e-3 of eps at scale 3.5) for 0.04 ms per forward (profiles/r04_gn_parts.log).  The VAE decoder keeps it.
+    cx.gn_parts = getenv("DMX_UNET_GN_PARTS") != nullptr;
     GnParts curp = gn_parts_new(cx, B, (size_t)H * W, pad8(boc[0]));
     {
       const size_t mk = A.mark();
@@ -575,7 +580,7 @@ struct UNet : Model {
         const bool fold = up2x && H2 == 2 * H && W2 == 2 * W;
         GnParts upp;
         float* ubuf[4] = {nullptr, nullptr, nullptr, nullptr};
-        if (gn_parts_wanted((size_t)H2 * W2)) for (int q = 0; q < (fold ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, fold ? (size_t)H * W : (size_t)H2 * W2, b.sampler.Cop);
+        if (gn_parts_wanted(cx, (size_t)H2 * W2)) for (int q = 0; q < (fold ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, fold ? (size_t)H * W : (size_t)H2 * W2, b.sampler.Cop);
         else upp.n = -1;
         const size_t mk = A.mark();
         if (fold) {

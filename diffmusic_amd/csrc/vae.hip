@@ -156,7 +156,7 @@ struct VaeDecoder : Model {
         // partial sums of the upsampler's output: one region per output-parity launch (each covers P low-resolution positions per image)
         GnParts up;
         float* ubuf[4] = {nullptr, nullptr, nullptr, nullptr};
-        if (gn_parts_wanted(P2)) for (int q = 0; q < (up2x ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, up2x ? P : P2, up_conv[i].Cop);
+        if (gn_parts_wanted(cx, P2)) for (int q = 0; q < (up2x ? 4 : 1); ++q) ubuf[q] = gn_part_alloc(cx, B, up2x ? P : P2, up_conv[i].Cop);
         else up.n = -1;
         const size_t mk = A.mark();
         Epi e;
@@ -209,8 +209,13 @@ struct VaeDecoder : Model {
     act_t* gn = A.bf(B * P * norm_out.g.C);
     act_t* g = A.bf(B * P * norm_out.g.C);
     CRUN(dmx_pad_col8_act(dmel, g8, (long long)B * P, st));
-    CRUN(conv_bwd_2d(conv_out, g8, gn, B, H, W, e, st));
-    CTRY(norm_out.bwd(cx, final_x, gn, nullptr, g, B, (int)P, 1, t_norm_out));
+    {
+      Epi eo;
+      float* pbo = norm_out.bwd_epi(cx, eo, final_x, B, P, 1, t_norm_out);
+      CRUN(conv_bwd_2d(conv_out, g8, gn, B, H, W, eo, st));
+      const GnParts bpo = norm_out.bwd_parts(cx, pbo, P);
+      CTRY(norm_out.bwd(cx, final_x, gn, nullptr, g, B, (int)P, 1, t_norm_out, &bpo));
+    }
     for (int i = nb - 1; i >= 0; --i) {
       const int ch = up_ch[i];
       if (i != nb - 1) {   // upsampler of block i sits after its resnets: undo it first

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD / EPI_ROWSTATS / EPI_GNSTATS: colsum, ln_eps, rowstats_in, rowstats_out, nslots, gn_part) */
+#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD / EPI_ROWSTATS / EPI_GNSTATS / EPI_GNBWD: colsum, ln_eps, rowstats_in, rowstats_out, nslots, gn_part, gnb_*) */
 #define DMX_MAX_STAGES 8
 
 typedef struct dmx_model dmx_model; /* opaque network handle (weights repacked for MFMA) */
@@ -237,6 +237,12 @@ size_t dmx_groupnorm_part_floats(int B, int P, int N);
 int dmx_groupnorm_parts_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
                             int B, int P, int C, int G, float eps, int silu, int nreg, float* const* part, const int* geom, void* stream);
 int dmx_gemm_last_tile_rows_raw(void);
+/* GroupNorm(+SiLU) backward (input gradient): the two per-group sums from EPI_GNBWD partial sums of the dgrad launch that produced dy
+ * (nreg regions, as above) or, with nreg == 0, from the classic pass over x and dy.  stats / scale / shift: the forward's outputs;
+ * k0, k1: (B, C) fp32 scratch; partial: dmx_groupnorm_scratch_floats(B, C, G) floats (used when nreg == 0); add: optional tensor added to dx. */
+int dmx_groupnorm_bwd_raw(const void* x, const void* dy, const void* add, void* dx, const float* stats, const float* scale, const float* shift,
+                          float* k0, float* k1, float* partial, int B, int P, int C, int G, int silu, int nreg, float* const* part,
+                          const int* geom, void* stream);
 
 #ifdef __cplusplus
 }

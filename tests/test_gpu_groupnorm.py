@@ -156,3 +156,60 @@ def test_groupnorm_parts_over_a_concatenation_and_parity_regions():
     xg = xf.reshape(B, P, G, Cc // G)
     assert torch.allclose(stats[..., 0], xg.mean(dim=(1, 3)), atol=3e-5, rtol=1e-5)
     assert torch.allclose(stats[..., 1], (xg.var(dim=(1, 3), unbiased=False) + eps).rsqrt(), atol=0, rtol=3e-5)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 8, 10, 11, 12, 14, 19, 3, 6])
+@pytest.mark.parametrize("B,P,K,Cc,silu", [(3, 1003, 64, 256, 1), (2, 4000, 72, 128, 1), (5, 700, 128, 640, 0)])
+def test_groupnorm_backward_from_producer_partial_sums(cfg, B, P, K, Cc, silu):
+    """EPI_GNBWD -> gn_bwd_parts_finalize_kernel: the dgrad launch that produces dy of a GroupNorm(+SiLU) writes the two backward sums
+    per wave tile / image / quad from its epilogue (sum dxh, sum dxh (x - mean)); the backward then needs no pass over x and dy for them.
+    Checked against torch autograd of group_norm(+silu) and against the classic path on the same tensors, with image boundaries inside
+    wave tiles (P = 1003 / 700) and 4 / 8 / 20 channels per group."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(cfg * 11 + P)
+    G, eps = 32, 1e-5
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = (torch.randn(B, P, Cc, generator=g) * 1.3 + 2.0 * torch.randn(B, 1, Cc, generator=g)).to(L.act_dtype()).cuda()   # per-channel offsets: large group means
+    gamma = (torch.randn(Cc, generator=g) * 0.3 + 1.0).cuda()
+    beta = (torch.randn(Cc, generator=g) * 0.2).cuda()
+    y = torch.empty_like(x)
+    stats, scale, shift = torch.empty(B, G, 2, device="cuda"), torch.empty(B, Cc, device="cuda"), torch.empty(B, Cc, device="cuda")
+    partial = torch.empty(L.lib().dmx_groupnorm_scratch_floats(B, Cc, G), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    L.check(L.lib().dmx_groupnorm_raw(p(x), p(y), p(gamma), p(beta), p(stats), p(scale), p(shift), p(partial), B, P, Cc, G, eps, silu, st), "gn")
+    # dy = a 1x1 "dgrad" GEMM over images of P pixels, with EPI_GNBWD
+    a = torch.randn(B * P, K, generator=g).to(L.act_dtype()).cuda()
+    w = (torch.randn(Cc, K, generator=g) / K ** 0.5).to(L.act_dtype()).cuda()
+    dy = torch.empty(B * P, Cc, dtype=L.act_dtype(), device="cuda")
+    part = torch.full((L.lib().dmx_groupnorm_part_floats(B, P, Cc),), float("nan"), device="cuda")
+    d = L.GemmDesc()
+    d.Z = d.Zi = 1
+    d.sy = d.sx = d.osy = d.osx = 1
+    d.alpha = 1.0
+    for k, v in dict(A=a, W=w, C=dy, gn_part=part, gnb_x=x, gnb_scale=scale, gnb_shift=shift, gnb_stats=stats).items():
+        setattr(d, k, v.data_ptr())
+    for k, v in dict(M=B * P, N=Cc, K=K, ldw=K, Hi=1, Wi=P, Ci=K, lda=K, Hq=1, Wq=P, ntaps=1, Ho=1, Wo=P, ldc=Cc, ldr=Cc, ldx=Cc, ldc2=Cc,
+                     gnb_ldx=Cc, gnb_silu=silu, gnb_cpg=Cc // G, flags=L.EPI_GNBWD, tile_cfg=cfg).items():
+        setattr(d, k, v)
+    L.check(L.lib().dmx_gemm_raw(C.byref(d), C.sizeof(d), st), "gemm")
+    tm = L.lib().dmx_gemm_last_tile_rows_raw()
+    assert tm in (32, 48, 64, 96, 128), tm
+    add = torch.randn(B, P, Cc, generator=g).to(L.act_dtype()).cuda()
+    k0, k1 = torch.empty(B, Cc, device="cuda"), torch.empty(B, Cc, device="cuda")
+    dx_parts, dx_classic = torch.empty_like(x), torch.empty_like(x)
+    geom = (C.c_int * 6)(tm, P, Cc // 4, 0, Cc // 4, 0)
+    L.check(L.lib().dmx_groupnorm_bwd_raw(p(x), p(dy), p(add), p(dx_parts), p(stats), p(scale), p(shift), p(k0), p(k1), p(partial), B, P, Cc, G,
+                                          silu, 1, (C.c_void_p * 1)(part.data_ptr()), geom, st), "gn_bwd parts")
+    L.check(L.lib().dmx_groupnorm_bwd_raw(p(x), p(dy), p(add), p(dx_classic), p(stats), p(scale), p(shift), p(k0), p(k1), p(partial), B, P, Cc, G,
+                                          silu, 0, None, None, st), "gn_bwd classic")
+    torch.cuda.synchronize()
+    xr = x.float().requires_grad_(True)
+    yr = F.group_norm(xr.transpose(1, 2), G, gamma, beta, eps).transpose(1, 2)
+    if silu:
+        yr = F.silu(yr)
+    (gref,) = torch.autograd.grad((yr * dy.float().reshape(B, P, Cc)).sum(), xr)
+    gref = gref + add.float()
+    rel = lambda u, v: ((u.float() - v.float()).norm() / v.float().norm()).item()
+    assert rel(dx_classic, gref) < 2e-3
+    assert rel(dx_parts, gref) < 2e-3
+    assert rel(dx_parts, dx_classic) < 1e-3

@@ -132,6 +132,7 @@ def test_unet_groupnorm_from_producer_partial_sums(cfg_name, monkeypatch):
         ref = UNetMusicLDM(**{k: v for k, v in cfg.items() if k != "attn_cross_dims"}, attn_cross_dims=(None, 48, 64))
         okw = dict(encoder_hidden_states=c0, encoder_hidden_states_1=c1, encoder_attention_mask_1=torch.ones(B, 12))
     ref.load_state_dict(sd, strict=True)
+    monkeypatch.setenv("DMX_UNET_GN_PARTS", "1")            # (off by default in the U-Net: CFG rows of equal conditioning)
     out = eng.forward(*args).clone()
     monkeypatch.setenv("DMX_NO_GN_PARTS", "1")
     out_classic = eng.forward(*args).clone()
