@@ -116,6 +116,7 @@ enum {
                         // reported by dmx_gemm_last_tile_rows()); the consumer's GroupNorm needs no statistics pass over the tensor
   EPI_GNBWD = 131072,   // the output is dy of a GroupNorm(+SiLU): also write the BACKWARD partial sums (sum dxh, sum dxh x per quad, slot layout of
                         // EPI_GNSTATS) to gn_part, from gnb_x (the GroupNorm's input, row stride gnb_ldx), gnb_scale / gnb_shift ([image][N]) and gnb_stats
+  EPI_BIASINIT = 262144, // internal (set by the LDS-DMA launchers in place of EPI_BIAS): the accumulators start at bias[n] instead of zero
   EPI_SOFTBWD = 4096   // softmax backward fused into dP = dO . V^T:  v = (acc - rowbias[z * M + m]) * X[row, n]  (then alpha), with
                        // X = the probabilities P and rowbias = delta[row] = sum_c dO * O (fp32, one value per GEMM row and batch z; Zi = 1)
 };

@@ -4,6 +4,7 @@
 #pragma once
 #include "dmx_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 #include "gemm_epilogue.h"
 #include "conv_pair.h"
@@ -388,10 +389,24 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
   const int wm = wave / WN, wn = wave - wm * WN;
   const int lr = lane & 15, lq = lane >> 4;
   f32x4 acc[FM][FN];
+  // EPI_BIASINIT (set by the dispatcher in place of EPI_BIAS when nothing in the epilogue comes before the bias): the accumulators START
+  // at the channel bias -- the same number of register moves as clearing them, the bias registers die before the K loop, and the
+  // epilogue loses its bias term (2 us per 320 x 256 tile, profiles/r03_epilogue_ablation.log) -- loaded ahead of the ring's LDS-DMA
+  // issues so that the in-order vmcnt of their first use does not wait for a tile
+  if (p.flags & EPI_BIASINIT) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+      const int n = tn * BN + wn * TN + j * 16 + lq * 4;
+      const float4 bb = n < p.N ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < FM; ++i) acc[i][j] = f32x4{bb.x, bb.y, bb.z, bb.w};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // NSTAGE-deep ring: tiles ks+1 .. ks+NSTAGE-1 are in flight while tile ks is consumed.  Every iteration issues
   // exactly one stage (past the end the offsets are out of range -> zero fill, no memory traffic), so the vmcnt
@@ -598,6 +613,14 @@ int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
+  static const bool bias_init = getenv("DMX_NO_BIAS_INIT") == nullptr;
+  if (bias_init && (d.flags & EPI_BIAS) && d.bias && !(d.flags & (EPI_MASK | EPI_MASKBITS | EPI_SOFTBWD | EPI_LNFOLD))) {
+    // nothing precedes the bias in the epilogue's order (mask -> bias -> residual -> alpha ...): start the accumulators at it instead
+    GemmDesc q = d;
+    q.flags = (q.flags & ~EPI_BIAS) | EPI_BIASINIT;
+    hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, EM, LNF>), grid, dim3(NT), SMEM, stream, q);
+    return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, WM, WN, NSTAGE, EM, LNF>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
