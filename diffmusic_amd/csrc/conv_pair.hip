@@ -200,6 +200,19 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
 #pragma unroll
       for (int n = 0; n < FN; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
+  // EPI_BIASINIT: the stage's accumulators start at its channel bias (the bias registers die here, before the K loop)
+  auto init_acc = [&](const GemmDesc& d) {
+    if (C < 128 && (d.flags & EPI_BIASINIT)) {
+#pragma unroll
+      for (int n = 0; n < FN; ++n) {
+        const float4 bb = *reinterpret_cast<const float4*>(d.bias + cg * 64 + n * 16 + lq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][n] = f32x4{bb.x, bb.y, bb.z, bb.w};
+      }
+    } else {
+      zero_acc();
+    }
+  };
   using Frags = PairFrags<FN>;
   const unsigned xlane = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(slab + (rg * 64 + lr) * PITCH + lq * 16);
   const unsigned wlane0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(ring + (cg * 64 + lr) * 128 + (((0 * 4 + lq) ^ (lr & 7)) << 4));
@@ -309,7 +322,7 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   for (int i = 0; i < 4 * FN; ++i) rpre[i] = make_uint2(0, 0);
   if (!single) {
     // ---- stage A: 256 intermediate rows, row i <-> t = t0 - loB + i
-    zero_acc();
+    init_acc(P.a);
     run_stage(false, stepsA, 0);
     DMX_STAMP(2);
     // stage A's channel bias: fetched ONCE, here, for all row fragments.  Inside the tail loop below every iteration paid its own L2
@@ -389,7 +402,7 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
 
   // ---- stage B: output row r <-> t = t0 + r reads intermediate rows r + (tap offset + loB)
   DMX_STAMP(3);
-  zero_acc();
+  init_acc(P.b);
   run_stage(true, stepsB, stepsA);
   __syncthreads();
   DMX_STAMP(4);
@@ -497,6 +510,13 @@ long long pair_params(const GemmDesc* a, const GemmDesc& b, PairParams& P, doubl
   P.T = b.Wq;
   P.BMo = a ? PAIR_ROWS - hb.lo - hb.hi : PAIR_ROWS;
   P.nb = cdiv(P.T, P.BMo);
+  // channel biases that nothing precedes in the epilogue order (no leaky-relu' mask: the forward pairs) become the INITIAL value of the
+  // stage's accumulators (EPI_BIASINIT): stage A loses an L2 round trip between its K loop and its tail, stage B the epilogue's bias term
+  static const bool bias_init = getenv("DMX_NO_BIAS_INIT") == nullptr;
+  if (bias_init && b.N < 128) {       // (the C = 128 instances spill 5 registers with it)
+    if ((P.b.flags & EPI_BIAS) && P.b.bias && !(P.b.flags & (EPI_MASK | EPI_MASKBITS))) P.b.flags = (P.b.flags & ~EPI_BIAS) | EPI_BIASINIT;
+    if (a && (P.a.flags & EPI_BIAS) && P.a.bias && !(P.a.flags & (EPI_MASK | EPI_MASKBITS))) P.a.flags = (P.a.flags & ~EPI_BIAS) | EPI_BIASINIT;
+  }
   P.r_from_slab = (a && (b.flags & EPI_RESID) && b.R == a->A && b.ldr == b.N) ? 1 : 0;
   P.a_tape_bits_only = (a && (a->flags & EPI_BITS2) && !a->C2) ? 1 : 0;
   const int nclips = b.M / P.T;
