@@ -69,14 +69,19 @@ class _Engine:
     def synth_state_dict(self, seed=0):
         return synth_state_dict(self.param_specs(), seed, self.kind, self._stride_of)
 
-    def load_state_dict(self, sd):
+    # tensors a real checkpoint of the same model may carry that this executor does not use
+    allow_unexpected = ()
+
+    def load_state_dict(self, sd, strict=False):
+        """strict=True (checkpoint directories): every tensor of the checkpoint must be one the configured architecture expects
+        (besides `allow_unexpected` prefixes); either way all missing / mis-shaped tensors are reported together (weights.check_manifest)."""
         lib = L.lib()
-        for name, shape in self.param_specs():
-            if name not in sd:
-                raise KeyError(f"state_dict is missing '{name}'")
+        from .weights import check_manifest
+        specs = self.param_specs()
+        check_manifest(specs, sd if strict else {n: sd[n] for n, _ in specs if n in sd}, f"{self.kind} ({type(self).__name__})",
+                       self.allow_unexpected)
+        for name, shape in specs:
             t = sd[name].detach().to(torch.float32).contiguous().cpu()
-            if tuple(t.shape) != tuple(shape):
-                raise ValueError(f"'{name}': expected shape {shape}, got {tuple(t.shape)}")
             L.check(lib.dmx_model_load_param(self._h, name.encode(), C.c_void_p(t.data_ptr()), t.numel()), name)
         with torch.cuda.device(self.device):
             L.check(lib.dmx_model_finalize(self._h, _stream()), "finalize")
@@ -96,6 +101,7 @@ class _Engine:
 class HifiGanEngine(_Engine):
     """`vocoder(mel)` of the reference (operator.py:126-130) + its input-gradient backward."""
     kind = "hifigan"
+    allow_unexpected = ("mean", "scale")                   # SpeechT5HifiGan buffers (normalize_before = False in the configs used)
 
     def __init__(self, config=None, device="cuda"):
         cfg = dict(HIFIGAN_DEFAULT)
@@ -153,6 +159,7 @@ class HifiGanEngine(_Engine):
 class VaeDecoderEngine(_Engine):
     """`vae.decode(z).sample` of the reference (scheduling_dps.py:195-197) + input-gradient backward."""
     kind = "vae"
+    allow_unexpected = ("encoder.", "quant_conv.")          # AutoencoderKL checkpoints carry the encoder too; the hot path decodes only
 
     def __init__(self, config=None, device="cuda"):
         cfg = dict(VAE_DEFAULT)

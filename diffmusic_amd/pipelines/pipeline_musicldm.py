@@ -55,7 +55,7 @@ class MusicLDMPipeline:
                 sd = {}
                 for f in files:
                     sd.update(load_file(os.path.join(repo_id, sub, f)))
-                eng.load_state_dict(sd)
+                eng.load_state_dict(sd, strict=True)          # fails with the full list of missing / mis-shaped / unknown tensors
         else:
             for i, eng in enumerate((unet, vae, voc)):
                 eng.load_state_dict(eng.synth_state_dict(seed=seed + i))

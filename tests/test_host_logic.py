@@ -166,3 +166,23 @@ def test_clap_text_frontend_glue():
         front.encode(["a", "b"], ["x"], True)
     with pytest.raises(TypeError):
         front.encode(["a", "b"], "x", True)
+
+
+def test_checkpoint_manifest_check_lists_everything():
+    """from_pretrained(<dir>) compares the checkpoint with the configured architecture's parameter manifest and reports every missing,
+    mis-shaped and unknown tensor in one error (the architectures of SURVEY.md Appendix A are recalled, not verified)."""
+    from diffmusic_amd.weights import check_manifest
+    specs = [("conv_in.weight", (128, 8, 3, 3)), ("conv_in.bias", (128,)), ("mid.attn.to_q.weight", (640, 640))]
+    good = {n: torch.zeros(s) for n, s in specs}
+    check_manifest(specs, good)
+    check_manifest(specs, dict(good, **{"encoder.conv_in.weight": torch.zeros(3)}), allow_unexpected=("encoder.",))
+    bad = dict(good)
+    del bad["conv_in.bias"]
+    bad["mid.attn.to_q.weight"] = torch.zeros(640, 1024)
+    bad["class_embedding.weight"] = torch.zeros(512, 512)
+    with pytest.raises(ValueError) as ei:
+        check_manifest(specs, bad, what="unet")
+    msg = str(ei.value)
+    assert "1 missing, 1 of another shape, 1 unexpected of 3 expected" in msg
+    assert "missing     conv_in.bias (128,)" in msg and "expected (640, 640), checkpoint has (640, 1024)" in msg
+    assert "unexpected  class_embedding.weight (512, 512)" in msg
