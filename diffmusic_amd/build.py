@@ -11,6 +11,8 @@ LIB = os.path.join(HERE, "lib", "libdiffmusic_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("DMX_EXTRA_FLAGS", "").split()
 
 
+# per-file additions (reasons: header note of the file)
+FILE_FLAGS = {"flash_attn.hip": ["-fno-honor-nans", "-fno-slp-vectorize"]}
 STAMP = os.path.join(OBJ, "flags.stamp")
 
 
@@ -18,7 +20,7 @@ def _flags_key(hipcc):
     """Everything besides the sources that decides what the objects contain: compiler path + the full flag list (DMX_EXTRA_FLAGS
     included).  A library built with other flags (e.g. an ablation build of a dev script) is rebuilt, never reused."""
     import hashlib
-    return hashlib.sha256(("\0".join([hipcc] + FLAGS)).encode()).hexdigest()
+    return hashlib.sha256(("\0".join([hipcc] + FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(FILE_FLAGS.items())])).encode()).hexdigest()
 
 
 def _stale(out, deps):
@@ -48,7 +50,7 @@ def build_library(force=False, verbose=False):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc, *FLAGS, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
