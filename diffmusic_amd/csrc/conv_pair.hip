@@ -543,6 +543,8 @@ long long pair_params(const GemmDesc* a, const GemmDesc& b, PairParams& P, doubl
 
 // a == nullptr: plain slab convolution of `b`.  Otherwise b.A must be the tensor stage `a` produces
 // (a.C2 when a carries EPI_LRELU2, else a.C); it is taken from LDS and, in the latter case, never written.
+// (DMX_PAIR_EXTRA_LDS: occupancy experiments only -- unused LDS bytes added to the request so that fewer workgroups share a CU)
+static int pair_extra_lds() { static const int v = [] { const char* e = getenv("DMX_PAIR_EXTRA_LDS"); return e ? atoi(e) : 0; }(); return v; }
 int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   if (!dmx_conv_pair_eligible(a, b)) return DMX_ERR_SHAPE;
   PairParams P;
@@ -554,8 +556,8 @@ int dmx_conv_pair_launch(const GemmDesc* a, const GemmDesc& b, hipStream_t st) {
   auto launch = [&](auto tag) {
     constexpr int CC = decltype(tag)::value;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<CC>::LDS_BYTES); attr = true; }
-    hipLaunchKernelGGL(conv_pair_kernel<CC>, dim3((unsigned)grid), dim3(PairCfg<CC>::NT), PairCfg<CC>::LDS_BYTES, st, P);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv_pair_kernel<CC>, hipFuncAttributeMaxDynamicSharedMemorySize, PairCfg<CC>::LDS_BYTES + (CC < 128 ? pair_extra_lds() : 0)); attr = true; }
+    hipLaunchKernelGGL(conv_pair_kernel<CC>, dim3((unsigned)grid), dim3(PairCfg<CC>::NT), PairCfg<CC>::LDS_BYTES + (CC < 128 ? pair_extra_lds() : 0), st, P);
   };
   if (C == 32) launch(std::integral_constant<int, 32>{});
   else if (C == 64) launch(std::integral_constant<int, 64>{});

@@ -1,1 +1,1 @@
-from .dataloader import WAVDataset, get_dataloader, get_dataset, register_dataset   # noqa: F401
+from .dataloader import MP3Dataset, WAVDataset, get_dataloader, get_dataset, register_dataset   # noqa: F401

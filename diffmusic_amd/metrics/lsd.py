@@ -2,7 +2,11 @@
 
 librosa is not a dependency here; the STFT it computes is restated: periodic Hann window of n_fft samples,
 hop_length stride, center=True with ZERO padding of n_fft // 2 on both sides (librosa >= 0.10 default
-pad_mode="constant"), one-sided rfft, 1 + L // hop frames."""
+pad_mode="constant"), one-sided rfft, 1 + L // hop frames.
+
+Two legs with the same definition: numpy float64 on the host (the reference's form: lists / arrays in), and -- for CUDA tensors --
+the HIP STFT-magnitude kernel (csrc/stft_mel.hip through SpectralFrontend.stft_mag, fp32) followed by device-side reductions, so a
+batch that is already on the GPU after generation is scored there."""
 import numpy as np
 
 
@@ -21,8 +25,36 @@ class LogSpectralDistance:
     def __init__(self, sample_rate=16000, n_fft=1024, hop_length=160, eps=1e-10):
         self.n_fft, self.hop_length, self.eps = n_fft, hop_length, eps
 
+    def _mag_gpu(self, x):
+        """(B, L) fp32 cuda -> (B, 1 + n_fft/2, 1 + L // hop) magnitudes with ZERO centre padding.  The kernel pads by reflection
+        (torch.stft): the clip is embedded in zeros, P >= n_fft/2 + 1 of them in front with P a multiple of the hop, so that the
+        reflected samples are zeros and frame i of the zero-padded clip is frame i + P / hop of the embedded one."""
+        import torch
+        from ..inverse_problem.operator import SpectralFrontend
+        if getattr(self, "_fe", None) is None:
+            self._fe = SpectralFrontend(16000, self.n_fft, self.hop_length, 64, "hann")
+        B, L = x.shape
+        half = self.n_fft // 2
+        P = -(-(half + 1) // self.hop_length) * self.hop_length
+        xp = torch.zeros(B, P + L + P, dtype=torch.float32, device=x.device)
+        xp[:, P:P + L] = x
+        k = P // self.hop_length
+        return self._fe.stft_mag(xp, xp.shape[1])[:, :, k:k + 1 + L // self.hop_length]
+
+    def _score_gpu(self, ref, est, output_mean):
+        import torch
+        ref = ref.float().reshape(-1, ref.shape[-1]).contiguous()
+        est = torch.nan_to_num(est.float().reshape(-1, est.shape[-1]), nan=0.0, posinf=1.0, neginf=-1.0).contiguous()
+        lr = torch.log10(self._mag_gpu(ref) + self.eps)
+        le = torch.log10(self._mag_gpu(est) + self.eps)
+        per_clip = ((lr - le) ** 2).mean(dim=1).sqrt().mean(dim=1)
+        return per_clip.mean() if output_mean else per_clip
+
     def score(self, audio_background, audio_eval, output_mean=True):
-        """(B, L) arrays -> mean over clips (or the (B,) vector) of mean_t sqrt(mean_f (log10|X| - log10|Y|)^2)."""
+        """(B, L) arrays -> mean over clips (or the (B,) vector) of mean_t sqrt(mean_f (log10|X| - log10|Y|)^2).
+        CUDA tensors in -> computed on the GPU, CUDA tensor out."""
+        if getattr(audio_background, "is_cuda", False) and getattr(audio_eval, "is_cuda", False):
+            return self._score_gpu(audio_background, audio_eval, output_mean)
         ref = np.asarray(audio_background)
         est = np.nan_to_num(np.asarray(audio_eval), nan=0.0, posinf=1.0, neginf=-1.0)
         lr = np.log10(_stft_mag(ref, self.n_fft, self.hop_length) + self.eps)

@@ -13,7 +13,15 @@ class MeanSquaredError:
         self.reduction = reduction
 
     def score(self, audio_background, audio_eval):
-        """Both arguments: sequences of 1-D clips (lengths may differ; each pair is compared on its common prefix)."""
+        """Both arguments: sequences of 1-D clips (lengths may differ; each pair is compared on its common prefix).
+        Two (B, L) CUDA tensors are scored on the GPU (CUDA scalar out)."""
+        if getattr(audio_background, "is_cuda", False) and getattr(audio_eval, "is_cuda", False):
+            import torch
+            n = min(audio_background.shape[-1], audio_eval.shape[-1])
+            ref = torch.nan_to_num(audio_background.float()[..., :n], nan=0.0, posinf=1.0, neginf=-1.0)
+            est = torch.nan_to_num(audio_eval.float()[..., :n], nan=0.0, posinf=1.0, neginf=-1.0)
+            per_clip = ((ref - est) ** 2).reshape(-1, n).mean(dim=1)
+            return per_clip.mean() if self.reduction == "mean" else per_clip.sum()
         per_clip = []
         for ref, est in zip(audio_background, audio_eval):
             ref, est = _sanitize(ref), _sanitize(est)
