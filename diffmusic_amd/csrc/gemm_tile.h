@@ -182,10 +182,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   const int lr = lane & 15, lq = lane >> 4;
 
   f32x4 acc[FM][FN];
+  // EPI_BIASINIT as in glds_tile below.  Here it is not about speed: the two kernel families must ROUND alike (bias first, then the
+  // products in K order), or a layer that runs on this kernel at batch 1 and on an LDS-DMA tile at batch 8 stops being bit-identical
+  // across batch sizes -- and one flipped leaky-relu sign in the vocoder tape moves its input gradient by percents
+  // (tests/test_gpu_batch_parity.py)
+  if (p.flags & EPI_BIASINIT) {
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int j = 0; j < FN; ++j) {
+      const int n = tn * BN + wn * TN + j * 16 + lq * 4;
+      float bb[4];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < 4; ++e) bb[e] = n + e < p.N ? p.bias[n + e] : 0.f;        // (N need not be a multiple of 4 on this kernel)
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = f32x4{bb[0], bb[1], bb[2], bb[3]};
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int nk = (p.K + BK - 1) / BK;
   load_tile(0);
@@ -636,6 +652,13 @@ int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
   }
   const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
+  static const bool bias_init = getenv("DMX_NO_BIAS_INIT") == nullptr;
+  if (bias_init && (d.flags & EPI_BIAS) && d.bias && !(d.flags & (EPI_MASK | EPI_MASKBITS | EPI_SOFTBWD | EPI_LNFOLD))) {
+    GemmDesc q = d;                           // same rule as launch_glds_t: every kernel of the family rounds alike
+    q.flags = (q.flags & ~EPI_BIAS) | EPI_BIASINIT;
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, EM, LNF>), grid, dim3(NT), SMEM, stream, q);
+    return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, EM, LNF>), grid, dim3(NT), SMEM, stream, d);
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
