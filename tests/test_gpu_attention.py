@@ -9,7 +9,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("B,heads,dh,Nq,Nk,bias", [(2, 8, 32, 1000, 1000, False), (1, 8, 48, 252, 252, False), (2, 8, 80, 64, 64, False),
                                                    (2, 4, 32, 300, 8, True), (1, 2, 64, 130, 77, True), (1, 1, 96, 129, 200, False),
-                                                   (3, 8, 32, 1000, 52, True)])
+                                                   (3, 8, 32, 1000, 52, True),
+                                                   # grids of more than 256 128-query workgroups: the two-query-tile form (QT = 2) of every
+                                                   # head-dim class, with ragged query / key tails and the biased (generic) block path
+                                                   (5, 8, 32, 1100, 1000, False), (5, 8, 32, 900, 333, True), (6, 6, 48, 1000, 200, False),
+                                                   (8, 5, 64, 1000, 129, True), (9, 4, 80, 1000, 96, False), (9, 4, 96, 1000, 70, True)])
 def test_flash_attention_forward(B, heads, dh, Nq, Nk, bias):
     from diffmusic_amd import _lib as L
     adt = L.act_dtype()
