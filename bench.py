@@ -34,6 +34,7 @@ SCHED_CFG = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, b
                  thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
                  timestep_spacing="leading", rescale_betas_zero_snr=False)
 SR, SECONDS, N_STEPS, ZETA, GUIDANCE_SCALE = 16000, 10, 200, 5e-4, 2.0
+DEFAULT_LANES = 1
 ALGO_TFLOP_PER_CLIP_STEP = 3.52        # BASELINE.md section 2 (U-Net 2x fwd + VAE fwd/dgrad + HiFi-GAN fwd/dgrad)
 PEAK_TFLOPS_16BIT = 2500.0             # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBPS = 8000.0                 # HBM3E (MI355X_MICROARCH.md)
@@ -113,6 +114,65 @@ def one_step(pipe, latents, t, cond, measurement, L):
                               vocoder=pipe.vocoder, original_waveform_length=L, ip_guidance_rate=b["rate"],
                               supervised_space="mel_spectrogram")
     return out.prev_sample, out.loss
+
+
+class Stepper:
+    """Advances the B clips of this rank through consecutive steps of the schedule: the plain loop (lanes = 1: U-Net, then the guided
+    step, for the whole batch, NaN test of the loss per step) or the product's clip lanes (diffmusic_amd/pipelines/lanes.py: the batch
+    cut into `lanes` contiguous groups whose U-Net forwards run under each other's guidance sweeps; same per-step NaN test, per lane)."""
+
+    def __init__(self, pipe, latents, cond, measurement, L, lanes, nan_check):
+        self.pipe, self.cond, self.measurement, self.L, self.nan_check = pipe, cond, measurement, L, nan_check
+        self.B = latents.shape[0]
+        self.n_lanes = max(1, min(int(lanes), self.B))
+        self.latents_plain = latents
+        self.lanes = None
+        if self.n_lanes > 1:
+            from diffmusic_amd.pipelines.lanes import Lane, LaneRunner, split_sizes
+            self.runner = LaneRunner(latents.device)
+            gens = pipe._bench["gens"]
+            self.lanes, o = [], 0
+            for n in split_sizes(self.B, self.n_lanes):
+                ids = list(range(o, o + n))
+                o += n
+                rows = ids + [self.B + k for k in ids]
+                c = {k: (v[rows].contiguous() if v is not None else None) for k, v in cond.items()}
+                m = measurement[ids].contiguous() if measurement.shape[0] == self.B and self.B > 1 else measurement
+                self.lanes.append(Lane(ids, latents[ids].contiguous(), c, m, [gens[k] for k in ids]))
+
+    @property
+    def latents(self):
+        return self.latents_plain if self.lanes is None else torch.cat([ln.latents for ln in self.lanes], dim=0)
+
+    def set_latents(self, latents):
+        if self.lanes is None:
+            self.latents_plain = latents
+        else:
+            for ln in self.lanes:
+                ln.latents = latents[ln.ids].contiguous()
+
+    def advance(self, ts):
+        """One step per entry of `ts` (host timesteps).  Returns (loss of the last step over all clips, number of steps with a NaN loss)."""
+        pipe, b = self.pipe, self.pipe._bench
+        if self.lanes is None:
+            nan_steps, loss = 0, None
+            for t in ts:
+                self.latents_plain, loss = one_step(pipe, self.latents_plain, t, self.cond, self.measurement, self.L)
+                if self.nan_check:        # the loop body's NaN test (pipeline_musicldm.py:741-742): one host sync per step
+                    nan_steps += int(bool(torch.isnan(loss).any()))
+            return loss, nan_steps
+
+        def unet_fn(ln, i):
+            return pipe._unet_eps(ln.latents, ts[i], ln.cond, b["gscale"], True)
+
+        def step_fn(ln, i, eps):
+            out = pipe.scheduler.step(eps, ts[i], ln.latents, eta=b["eta"], generator=ln.generator, measurement=ln.measurement, vae=pipe.vae,
+                                      vocoder=pipe.vocoder, original_waveform_length=self.L, ip_guidance_rate=b["rate"],
+                                      supervised_space="mel_spectrogram")
+            return out.prev_sample, out.loss
+        bad = self.runner.run(self.lanes, len(ts), unet_fn, step_fn, 1 if self.nan_check else 10 ** 9)
+        loss = torch.cat([ln.losses[-1].reshape(-1) for ln in self.lanes])
+        return loss, int(bad is not None)
 
 
 def cpu_model_string():
@@ -312,11 +372,16 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL over xGMI (default); gloo only to rehearse the "
                     "multi-rank path on a box with fewer GPUs than ranks (with --share-gpu)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (gloo backend only)")
+    ap.add_argument("--lanes", type=int, default=DEFAULT_LANES, help="clip lanes per GPU (diffmusic_amd/pipelines/lanes.py): the per-GPU batch is cut "
+                    "into this many groups and each group's U-Net forward runs under the other groups' guidance sweeps; 1 = the plain loop "
+                    "(U-Net, then the guided step, for the whole batch)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (and time the final gather through it) even at "
+                    "--gpus 1: the RCCL path at world size 1, in a fresh child process like every spawned rank")
     ap.add_argument("--workload", default="dps_inpainting", choices=sorted(WORKLOADS),
                     help="default = the headline config (BASELINE.json configs[1]); the others are the remaining GPU configs")
     args = ap.parse_args()
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and env_world == 1 and "RANK" not in os.environ:
+    if (args.gpus > 1 or args.force_dist) and env_world == 1 and "RANK" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:], 1 if args.share_gpu else args.gpus))
     world, rank, local = env_world, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
@@ -328,7 +393,8 @@ def main():
             print("[bench] --share-gpu is a rehearsal mode and needs --backend gloo (RCCL wants one device per rank)", file=sys.stderr)
             sys.exit(3)
         local = 0
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         torch.cuda.set_device(local)
         try:
             if args.backend == "nccl":
@@ -366,7 +432,7 @@ def main():
     latents0 = latents.clone()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -375,44 +441,38 @@ def main():
     # (library initialisation), and the first torch.isnan(...).any() of a process loads torch's elementwise kernels lazily (~30 ms: it
     # used to fall into the timed loop and read as "the first process on a box is 3-6 ms/step slower", 44.8 -> 41.0 ms over 10 steps).
     # The trajectory that is warmed up and timed below starts from the untouched latents.
+    nan_check = not args.no_nan_check
+    n_lanes = max(1, min(args.lanes, B))
+    stepper = Stepper(pipe, latents, pe2, measurement, L, n_lanes, nan_check)
     settle_ms = []
     if args.settle > 0:
-        lat_c = latents.clone()
         se0, se1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for i in range(args.settle):
             se0.record()
-            lat_c, loss_c = one_step(pipe, lat_c, ts[i % n_sched], pe2, measurement, L)
-            se1.record()
-            if not args.no_nan_check:        # the whole loop body, host check included: its torch kernels are loaded lazily on first use
-                bool(torch.isnan(loss_c).any())      # (measured: ~30 ms once per process on a fresh box -- 3 ms/step over a 10-step timed region)
+            stepper.advance([ts[i % n_sched]])          # the whole loop body, host NaN check included (its torch kernels load lazily:
+            se1.record()                                # measured ~30 ms once per process on a fresh box)
             torch.cuda.synchronize()
             settle_ms.append(se0.elapsed_time(se1))
-        del lat_c
+        stepper.set_latents(latents0)                   # the trajectory that is warmed up and timed below starts from the untouched latents
     k = 0
-    for _ in range(args.warmup):             # the same body as the timed loop below
-        latents, loss_w = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
-        if not args.no_nan_check:
-            bool(torch.isnan(loss_w).any())
-        k += 1
+    if args.warmup > 0:                      # the same body as the timed loop below
+        stepper.advance([ts[(k + j) % n_sched] for j in range(args.warmup)])
+        k += args.warmup
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    loss = None
-    nan_steps = 0
-    for _ in range(args.steps):
-        latents, loss = one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
-        if not args.no_nan_check:            # the loop body's NaN test (pipeline_musicldm.py:741-742): one host sync per step
-            nan_steps += int(bool(torch.isnan(loss).any()))
-        k += 1
+    loss, nan_steps = stepper.advance([ts[(k + j) % n_sched] for j in range(args.steps)])
+    k += args.steps
     ev1.record()
     barrier()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     tmax = torch.tensor([wall], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
+    latents = stepper.latents
     finite = bool(torch.isfinite(loss).all()) and bool(torch.isfinite(latents).all())
 
     # ---- after the loop: final decode of this rank's clips and the path's only collective, one all_gather of (B, L) waveforms
@@ -429,6 +489,7 @@ def main():
     torch.cuda.synchronize()
     gather_ms = 1e3 * (time.perf_counter() - tg)
     assert gathered.shape == (G, L)
+    gathered_equals_local = bool(torch.equal(gathered[parallel.shard_indices(G, rank, world)].to(audio.device), audio))   # this rank's rows came back bit-equal
     finite = finite and bool(torch.isfinite(gathered).all())
     final_decode_ms = e0.elapsed_time(e1)
 
@@ -437,7 +498,7 @@ def main():
     if not args.no_stage_times:
         from diffmusic_amd import profiling
         profiling.enable(events=True)
-        for _ in range(2):
+        for _ in range(2):                  # the plain loop body on the whole batch: stage times without overlap between stages
             one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
         stages = {kk: round(v, 3) for kk, v in profiling.stage_ms().items()}
         profiling.enable(events=False)
@@ -453,7 +514,7 @@ def main():
     import ctypes as C
     from diffmusic_amd import _lib as Lb
     Lb.lib().dmx_prof_begin()
-    one_step(pipe, latents, ts[k % n_sched], pe2, measurement, L)
+    stepper.advance([ts[k % n_sched]])       # as timed above: with clip lanes the launches have the lanes' shapes and run under overlap
     ms, fl = C.c_double(), C.c_double()
     n_launch = Lb.lib().dmx_prof_end(C.byref(ms), C.byref(fl))
     # headline config: the analytic count of BASELINE.md; other workloads: the FLOPs the launches actually issued
@@ -485,21 +546,19 @@ def main():
     # latents -- what run.py:317-332 sees per call, and several seconds of GPU time that an outside sampler can see
     full_traj = None
     if not args.no_full_trajectory:
-        lat_f = latents0.clone()
+        stepper.set_latents(latents0.clone())
         barrier()
         tf = time.perf_counter()
-        for i in range(n_sched):
-            lat_f, loss_f = one_step(pipe, lat_f, ts[i], pe2, measurement, L)
-            if not args.no_nan_check:
-                bool(torch.isnan(loss_f).any())
+        loss_f, _ = stepper.advance(list(ts[:n_sched]))
         torch.cuda.synchronize()
         t_loop = time.perf_counter() - tf
+        lat_f = stepper.latents
         mel_f = pipe.vae.decode(lat_f / pipe.vae.config.scaling_factor).sample
         audio_f = pipe.vocoder(mel_f.squeeze(1))[:, :L].float()
         torch.cuda.synchronize()
         t_all = time.perf_counter() - tf
         tm = torch.tensor([t_loop, t_all], dtype=torch.float64, device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         full_traj = {"steps": n_sched, "loop_wall_s": round(float(tm[0]), 4), "wall_s_with_final_decode": round(float(tm[1]), 4),
                      "steps_per_sec": round(n_sched / float(tm[0]) * (1 if strong else world), 4),
@@ -522,20 +581,24 @@ def main():
                   (" (BASELINE.json configs[1])" if is_headline else f" ({WORKLOADS[wl][6]})" if wl != "dps_inpainting" else " (configs[1] at another batch)")
         unit = (f"steps/s (strong scaling: one step advances all {G} clips of the job; value = K / wall)" if strong else
                 f"steps/s (weak scaling: one step advances a batch of {B} clips on one GPU; value = K / wall x {world} GPU(s))")
+        if n_lanes > 1:
+            unit += f"; the {B} clips of a GPU run as {n_lanes} clip lanes of {'+'.join(str(len(ln.ids)) for ln in stepper.lanes)}, staggered"
         res = {"metric": "denoising steps/sec (10 s clip, 200-step DPS)", "value": round(steps_per_s, 4) if finite else None,
                "unit": unit, "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * wall / args.steps, 3), "higher_is_better": True,
                "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-               "config": {"workload": wl_text, "global_batch": G, "clips_per_gpu": B,
+               "config": {"workload": wl_text, "global_batch": G, "clips_per_gpu": B, "lanes": n_lanes,
                           "clip_steps_per_sec": round(clip_steps, 3), "parallelism": f"clip-sharded x{world} ({'RCCL' if args.backend == 'nccl' else 'gloo REHEARSAL'} world size {world}, no per-step collective)",
                           "device_ms_per_step": round(dev_ms / args.steps, 3), "finite": finite, "nan_steps": nan_steps,
                           "nan_check_per_step": not args.no_nan_check,
                           "settle_steps": len(settle_ms), "settle_first3_ms": [round(v, 2) for v in settle_ms[:3]], "settle_last3_ms": [round(v, 2) for v in settle_ms[-3:]], "final_loss_clip0": float(loss.reshape(-1)[0]),
                           "cached_reference_transform": bool(getattr(op, "cache_reference", False)),
                           "launched_by": "bench.py spawn" if os.environ.get("DMX_BENCH_SPAWNED") else ("torch.distributed.run" if world > 1 else "single process")},
-               "after_loop": {"final_decode_ms": round(final_decode_ms, 3), "gather_ms": round(gather_ms, 3) if world > 1 else 0.0,
+               "after_loop": {"final_decode_ms": round(final_decode_ms, 3), "gather_ms": round(gather_ms, 3) if use_dist else 0.0,
                               "gather_bytes_per_rank": int(audio.numel() * 4), "gather_world_size": world,
-                              "collective": "all_gather of (clips_per_gpu, 160000) fp32 waveforms, once per call" if world > 1 else "none (single rank)"},
+                              "collective": (f"all_gather of (clips_per_gpu, 160000) fp32 waveforms, once per call ({'RCCL' if args.backend == 'nccl' else 'gloo'}, world size {world})"
+                                             if use_dist else "none (single rank, torch.distributed not initialised)"),
+                              "gathered_equals_local": gathered_equals_local},
                "full_trajectory": full_traj, "stage_ms": stages, "mel_path": mel_path, "roofline": roofline}
         if world == 1 and not args.no_cpu_baseline and wl == "dps_inpainting" and not strong:
             host_cpus, affinity, quota = cpu_share()
@@ -582,7 +645,7 @@ def main():
         if not finite:
             print(f"[bench] non-finite loss / latents / waveforms (nan_steps={nan_steps}): value set to null", file=sys.stderr)
             rc = 4
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     sys.exit(rc)

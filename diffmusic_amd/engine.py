@@ -90,11 +90,13 @@ class _Engine:
         return self
 
     def _workspace(self, key, nbytes):
-        ws = self._ws.get(key)
+        """One byte buffer per executor, grown to the largest request so far (calls of different batch sizes alternate when the
+        clip lanes of a call are of unequal size: no reallocation per call).  The launches that use it are stream-ordered."""
+        ws = self._ws.get("buf")
         if ws is None or ws.numel() < nbytes:
             self._ws.clear()
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-            self._ws[key] = ws
+            self._ws["buf"] = ws
         return ws
 
 

@@ -171,14 +171,21 @@ class BaseOperator:
         self._ref_cache = None
 
     def _ref(self, measurement, space, fn):
-        """`transform(y)` is constant over a trajectory: computed once per measurement TENSOR and supervised space.  The
-        cache entry holds the tensor itself (identity comparison + version counter), which also keeps its storage alive,
-        so a later measurement can never be handed the same address by the caching allocator and hit a stale entry."""
-        c = self._ref_cache
-        if not self.cache_reference or c is None or c[0] is not measurement or c[1] != measurement._version or c[2] != space:
-            c = (measurement, measurement._version, space, fn(_as_f32_cuda(measurement)))
-            self._ref_cache = c
-        return c[3]
+        """`transform(y)` is constant over a trajectory: computed once per measurement TENSOR and supervised space.  A cache
+        entry holds the tensor itself (identity comparison + version counter), which also keeps its storage alive, so a later
+        measurement can never be handed the same address by the caching allocator and hit a stale entry.  A few entries are kept
+        (most recent first): the clip lanes of one call (pipelines/lanes.py) alternate between their measurement tensors."""
+        if not self.cache_reference:
+            return fn(_as_f32_cuda(measurement))
+        cache = self._ref_cache
+        if cache is None:
+            cache = self._ref_cache = []
+        for c in cache:
+            if c[0] is measurement and c[1] == measurement._version and c[2] == space:
+                return c[3]
+        cache.insert(0, (measurement, measurement._version, space, fn(_as_f32_cuda(measurement))))
+        del cache[4:]
+        return cache[0][3]
 
     def guidance(self, wav, length, measurement, supervised_space):
         raise NotImplementedError

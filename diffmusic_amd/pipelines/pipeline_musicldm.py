@@ -40,6 +40,8 @@ class MusicLDMPipeline:
         self.device = torch.device("cuda")
         self.nan_check_every = 1          # host check of the loss every k steps (reference: every step, :742)
         self.dedupe_cfg = False           # opt-in: run one U-Net pass when cond == uncond
+        self.lanes = 1                    # > 1: clip lanes, the loop software-pipelined over clip groups (pipelines/lanes.py)
+        self._lane_runner = None
 
     # ---- construction ---------------------------------------------------------------------
     @classmethod
@@ -154,10 +156,12 @@ class MusicLDMPipeline:
                  negative_prompt_embeds=None, return_dict=True, callback=None, callback_steps=1, cross_attention_kwargs=None,
                  output_type="np", measurement=None, optim_prompt=False, ip_guidance_rate=0.0005,
                  optim_prompt_learning_rate=0.0001, optim_outer_loop=1, show_progress=True, prompt_type=None,
-                 supervised_space="mel_spectrogram", shard=False, group=None):
+                 supervised_space="mel_spectrogram", shard=False, group=None, lanes=None):
         """Reference signature (pipeline_musicldm.py:493-519) plus `shard` / `group` (extension): with
         torch.distributed initialised, `shard=True` (or a process `group`) makes every rank run clips k = rank, rank + G, ... of
-        the batch and all-gathers the finished waveforms once at the end (RCCL over xGMI); every rank returns all B clips."""
+        the batch and all-gathers the finished waveforms once at the end (RCCL over xGMI); every rank returns all B clips.
+        `lanes` (default `self.lanes`): > 1 runs this rank's clips as that many clip lanes whose U-Net forwards are hidden under
+        each other's guidance sweeps (pipelines/lanes.py); a lane's clips see exactly a call on those clips alone."""
         front = getattr(self, "text_frontend", None)
         do_cfg = guidance_scale > 1.0
         if prompt_embeds is None:
@@ -217,7 +221,20 @@ class MusicLDMPipeline:
         extra = self.prepare_extra_step_kwargs(generator, eta)
         self.last_losses = []
         self.nan_restarts = 0
-        if B > 0:
+        n_lanes = int(self.lanes if lanes is None else lanes)
+        if B > 0 and n_lanes > 1 and B > 1:
+            if callback is not None:
+                raise ValueError("lanes > 1 cannot serve `callback(i, t, latents)`: the clip groups are at different steps at any one time")
+            if isinstance(generator, torch.Generator) and eta > 0 or (isinstance(generator, torch.Generator) and
+                                                                      self.scheduler.mode in ("dsg", "diffmusic")):
+                raise ValueError("lanes > 1 with per-step noise needs one generator per clip (a list of length B): one shared "
+                                 "generator would be drawn from in another order than by the whole batch")
+            latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, latents)
+            for _ in range(optim_outer_loop):
+                latents = self._denoise_lanes(n_lanes, latents, pe, do_cfg, guidance_scale, measurement, timesteps, generator, eta,
+                                              original_waveform_length, ip_guidance_rate, supervised_space, optim_prompt,
+                                              optim_prompt_learning_rate, nlat, height, show_progress)
+        elif B > 0:
             latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, latents)
             init_latents = latents
             init_pe = pe
@@ -285,6 +302,66 @@ class MusicLDMPipeline:
         if not return_dict:
             return (audio,)
         return AudioPipelineOutput(audios=audio)
+
+    def _denoise_lanes(self, n_lanes, latents, pe, do_cfg, guidance_scale, measurement, timesteps, generator, eta, length, rate,
+                       supervised_space, optim_prompt, optim_lr, nlat, height, show_progress):
+        """The loop of `__call__` (NaN-retry included) over clip lanes.  Lane k holds a contiguous group of this call's clips with
+        their conditioning rows (both halves of the CFG batch), measurement rows and generators; every lane-step is the same
+        `_unet_eps` + `scheduler.step` the plain loop makes, on the lane's stream (pipeline_musicldm.py:690-758)."""
+        from .lanes import Lane, LaneRunner, split_sizes
+        B, device = latents.shape[0], latents.device
+        if self._lane_runner is None or self._lane_runner.device != device:
+            self._lane_runner = LaneRunner(device)
+        runner = self._lane_runner
+        sizes = split_sizes(B, n_lanes)
+        groups, o = [], 0
+        for n in sizes:
+            groups.append(list(range(o, o + n)))
+            o += n
+
+        def make_lanes(lat):
+            out = []
+            for ids in groups:
+                rows = ids + [B + k for k in ids] if do_cfg else ids
+                cond = {k: (v[rows].contiguous() if v is not None else None) for k, v in pe.items()}
+                meas = measurement
+                if measurement is not None and measurement.shape[0] == B and B > 1:
+                    meas = measurement[ids].contiguous()
+                gen = [generator[k] for k in ids] if isinstance(generator, (list, tuple)) else generator
+                out.append(Lane(ids, lat[ids].contiguous(), cond, meas, gen))
+            return out
+
+        def unet_fn(ln, i):
+            t = timesteps[i]
+            return self._unet_eps(self.scheduler.scale_model_input(ln.latents, t), t, ln.cond, guidance_scale, do_cfg)
+
+        def step_fn(ln, i, eps):
+            t = timesteps[i]
+            extra = self.prepare_extra_step_kwargs(ln.generator, eta)
+            if optim_prompt and t % 30 == 1:
+                ln.cond = self._optim_prompt_step(eps, t, ln.latents, ln.cond, ln.measurement, length, optim_lr, supervised_space, extra)
+            out = self.scheduler.step(eps, t, ln.latents, measurement=ln.measurement, original_waveform_length=length, vae=self.vae,
+                                      vocoder=self.vocoder, ip_guidance_rate=rate, ditto_optimizer=None, init_latents=None,
+                                      supervised_space=supervised_space, **extra)
+            return out.prev_sample.detach(), out.loss
+
+        retry = 10
+        while True:
+            lanes = make_lanes(latents)
+            bar = None
+            if show_progress:
+                from tqdm import tqdm
+                bar = tqdm(total=len(timesteps))
+            with bar if bar is not None else contextlib.nullcontext():
+                bad = runner.run(lanes, len(timesteps), unet_fn, step_fn, self.nan_check_every if retry >= 0 else 10 ** 9,
+                                 (lambda i: bar.update()) if bar is not None else None)
+            n_done = min(len(ln.losses) for ln in lanes)
+            self.last_losses.extend(torch.cat([ln.losses[i].reshape(-1) for ln in lanes]) for i in range(n_done))
+            if bad is None or retry < 0:
+                return torch.cat([ln.latents for ln in lanes], dim=0)
+            retry -= 1                                                                  # NaN-retry (:741-756): all clips restart
+            self.nan_restarts += 1
+            latents = self.prepare_latents(B, nlat, height, torch.float32, device, generator, None)
 
     assume_uncond_equals_cond = False      # True: prompt_embeds without negative_prompt_embeds means prompt == "" (no warning)
 
