@@ -338,8 +338,9 @@ def spawn_ranks(n, argv, need_gpus, timeout_s=3300.0):
         bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
         if not bad:
             return 0
-        early = time.monotonic() - (deadline - timeout_s) < 20.0          # failed inside the rendezvous window, not in the run
-        if (any(rc == 98 for _, rc in bad) or (early and rcs[0] not in (0, 3, 4))) and attempt < 2:   # EADDRINUSE (rank 0, see main) or a lost rendezvous: new port, once more
+        # only rendezvous failures are retried (exit codes 98 = EADDRINUSE, 97 = init_process_group raised; see main): any other early
+        # exit -- an import error, a bad argument -- is deterministic and is reported once
+        if any(rc in (97, 98) for _, rc in bad) and attempt < 2:
             print(f"[bench] rendezvous on port {port} failed (exit codes {bad}); retrying on another port", file=sys.stderr)
             continue
         print(f"[bench] ranks failed: {bad}", file=sys.stderr)
@@ -404,7 +405,9 @@ def main():
         except Exception as e:                                   # noqa: BLE001
             if "address already in use" in str(e).lower() or "EADDRINUSE" in str(e):
                 sys.exit(98)                                     # spawn_ranks retries on another port
-            raise
+            import traceback
+            traceback.print_exc()
+            sys.exit(97)                                         # the rendezvous itself failed (e.g. a foreign listener on a stolen port): retried too
         if dist.get_world_size() != args.gpus:
             print(f"[bench] only {dist.get_world_size()} of {args.gpus} ranks joined", file=sys.stderr)
             sys.exit(3)

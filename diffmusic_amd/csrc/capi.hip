@@ -153,10 +153,16 @@ size_t dmx_groupnorm_part_floats(int B, int P, int N) { return dmx_gn_part_float
 int dmx_groupnorm_parts_raw(const void* x, void* y, const float* gamma, const float* beta, float* stats, float* scale, float* shift,
                             int B, int P, int C, int G, float eps, int silu, int nreg, float* const* part, const int* geom, void* stream) {
   if (nreg < 1 || nreg > 8) { dmx_set_error("groupnorm_parts: 1..8 regions"); return DMX_ERR_SHAPE; }
+  // this entry point has no scratch for the classic statistics pass: everything that would make dmx_groupnorm_fwd fall back to it is refused
+  if (G <= 0 || C % G || ((C / G) & 3)) { dmx_set_error("groupnorm_parts: channels per group must be a multiple of 4 (C %d, G %d)", C, G); return DMX_ERR_SHAPE; }
   GnParts gp;
   for (int i = 0; i < nreg; ++i) {
     GnRegion r;
     r.part = part[i]; r.tm = geom[i * 6]; r.P = geom[i * 6 + 1]; r.nq = geom[i * 6 + 2]; r.qoff = geom[i * 6 + 3]; r.cq = geom[i * 6 + 4];
+    if (!r.part || r.tm < 32 || r.P < r.tm || r.nq <= 0 || r.cq <= 0 || r.cq > r.nq || r.qoff < 0 || r.qoff + r.cq > C / 4) {
+      dmx_set_error("groupnorm_parts: region %d: tm %d, P %d, nq %d, qoff %d, cq %d do not describe a producer launch of this tensor", i, r.tm, r.P, r.nq, r.qoff, r.cq);
+      return DMX_ERR_SHAPE;
+    }
     gp.r[gp.n++] = r;
   }
   const int rc = dmx_groupnorm_fwd((const act_t*)x, (act_t*)y, gamma, beta, stats, scale, shift, nullptr, B, P, C, G, eps, silu, ST(stream), &gp);
@@ -171,10 +177,15 @@ int dmx_groupnorm_bwd_raw(const void* x, const void* dy, const void* add, void* 
                           float* k0, float* k1, float* partial, int B, int P, int C, int G, int silu, int nreg, float* const* part,
                           const int* geom, void* stream) {
   if (nreg < 0 || nreg > 8) { dmx_set_error("groupnorm_bwd: 0..8 regions"); return DMX_ERR_SHAPE; }
+  if (nreg > 0 && !partial && (G <= 0 || C % G || ((C / G) & 3))) { dmx_set_error("groupnorm_bwd: regions need channels per group % 4 == 0, or scratch for the classic pass"); return DMX_ERR_SHAPE; }
   GnParts gp;
   for (int i = 0; i < nreg; ++i) {
     GnRegion r;
     r.part = part[i]; r.tm = geom[i * 6]; r.P = geom[i * 6 + 1]; r.nq = geom[i * 6 + 2]; r.qoff = geom[i * 6 + 3]; r.cq = geom[i * 6 + 4];
+    if (!r.part || r.tm < 32 || r.P < r.tm || r.nq <= 0 || r.cq <= 0 || r.cq > r.nq || r.qoff < 0 || r.qoff + r.cq > C / 4) {
+      dmx_set_error("groupnorm_bwd: region %d does not describe a producer launch of this tensor", i);
+      return DMX_ERR_SHAPE;
+    }
     gp.r[gp.n++] = r;
   }
   return dmx_groupnorm_bwd((const act_t*)x, (const act_t*)dy, (const act_t*)add, (act_t*)dx, stats, scale, shift, k0, k1, partial, B, P, C, G,

@@ -347,13 +347,17 @@ __global__ __launch_bounds__(256) void gn_finalize_apply_kernel(const act_t* __r
 // M2 = sum v^2 - (sum v)^2 / n over at most tm x C/G values -- and the items are Chan-combined in two sweeps (mean first, then
 // M2 + n (mean_i - mean)^2), like the chunk partials of gn_partial_kernel / gn_finalize_kernel.
 // rows of image b inside slot j of region R, and the slot count of image b
+// (the producers lay their wave tiles out per image -- an image whose row count is no multiple of the slot rows gets its own, image-aligned
+// M tiling, gemm_glds_kernel -- so slot j of ANY image covers its rows [j tm, (j + 1) tm): a clip's statistics do not depend on its
+// position in the batch or on the other clips)
 __device__ __forceinline__ int gn_parts_rows(const GnRegion& R, int b, int j) {
-  const int k = j + (b * R.P) / R.tm;
-  const int lo = max(k * R.tm, b * R.P), hi = min((k + 1) * R.tm, (b + 1) * R.P);
-  return hi > lo ? hi - lo : 0;
+  (void)b;
+  const int left = R.P - j * R.tm;
+  return left < R.tm ? (left > 0 ? left : 0) : R.tm;
 }
 __device__ __forceinline__ int gn_parts_nslots(const GnRegion& R, int b) {
-  return ((b + 1) * R.P - 1) / R.tm - (b * R.P) / R.tm + 1;
+  (void)b;
+  return (R.P + R.tm - 1) / R.tm;
 }
 // quads [q0, q1) of region R that belong to group g (cpg channels per group)
 __device__ __forceinline__ void gn_parts_quads(const GnRegion& R, int g, int cpg, int& q0, int& q1) {

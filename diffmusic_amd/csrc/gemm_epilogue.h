@@ -152,17 +152,19 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
     const int n = n0 + j * 16 + lq * 4;
     bcol[j] = ((flags & EPI_BIAS) && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  // EPI_GNSTATS: (sum v, sum v^2) of the STORED 16-bit values per 4-channel quad over the rows of this wave tile, split at the image
-  // boundary when the tile straddles two images (rows per image = HqWq).  A lane of the row-major phase owns 8 channels = 2 quads of
-  // RPI-strided rows: gs[0..3] = (s, q) of its two quads for the first image, gs[4..7] for the second.  Reduced over the lanes of a
-  // column chunk after the last chunk and written to slot (image, wave tile index inside the image); gn_parts_kernel (elementwise.hip)
-  // Chan-combines the slots.  Taken from the LDS-staged tile stage_out leaves behind (like emit_bits): the values GroupNorm will read,
-  // no accumulator registers held longer.
-  float gs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  constexpr int GN_TM = FM * 16;
+  // EPI_GNSTATS: (sum v, sum v^2) of the STORED 16-bit values per 4-channel quad and SLOT of GN_SLOT = 64 consecutive rows of an image (the
+  // image's last slot may be shorter).  A slot is one row chunk of this epilogue: the statistics instantiations are the tiles with 64-row
+  // chunks and 64-column wave tiles (static_assert below), whose lanes own the same rows and columns of a chunk in the same order, so a
+  // slot's two sums are the same bits whichever of those tiles produced it -- the statistics of a clip depend neither on the batch size
+  // (other M, other tile choice) nor on its position in the batch.  A wave tile never holds rows of two images: either the rows per image
+  // (HqWq) are a multiple of its rows, or the launch tiles M per image (gemm_glds_kernel) and `mlimit` ends the tile at its image's last
+  // row.  A lane of the row-major phase owns 8 channels = 2 quads of RPI-strided rows: gs = (s, q) of its two quads, reduced over the lanes
+  // of a column chunk and written at the end of every row chunk; gn_parts_kernel (elementwise.hip) Chan-combines the slots.  Taken from the
+  // LDS-staged tile stage_out leaves behind (like emit_bits): the values GroupNorm will read, no accumulator registers held longer.
+  float gs[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int GN_SLOT = 64;
+  static_assert(!(GNS || GNB) || (CH == GN_SLOT && FN == 4), "GroupNorm statistics: 64-row chunks of 64-column wave tiles only (one summation order)");
   const int gn_b0 = (GNS || GNB) ? m0 / HqWq : 0;
-  const int gn_bnd = (gn_b0 + 1) * HqWq;                       // first GEMM row of the next image
-  const bool gn_straddle = gn_bnd < m0 + GN_TM && gn_bnd < mend;
   static_for<0, FM / IB>([&](auto H) {
     constexpr int h = decltype(H)::value;
     // ---- output row of each tile row this lane touches in the row-major phases
@@ -250,30 +252,35 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
 #ifndef DMX_BF16
       typedef _Float16 dmx_h2 __attribute__((ext_vector_type(2)));
       const dmx_h2 one = {(_Float16)1.0f, (_Float16)1.0f};
+#endif
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const uint4 v = *reinterpret_cast<const uint4*>(wl + (it * RPI + rr) * PITCH + cch * 16);
         if (orows[it] >= 0 && col_ok) {
+#ifndef DMX_BF16
           const dmx_h2 a0 = __builtin_bit_cast(dmx_h2, v.x), a1 = __builtin_bit_cast(dmx_h2, v.y);
           const dmx_h2 a2 = __builtin_bit_cast(dmx_h2, v.z), a3 = __builtin_bit_cast(dmx_h2, v.w);
           const float s0 = __builtin_amdgcn_fdot2(a0, one, __builtin_amdgcn_fdot2(a1, one, 0.f, false), false);
           const float q0 = __builtin_amdgcn_fdot2(a0, a0, __builtin_amdgcn_fdot2(a1, a1, 0.f, false), false);
           const float s1 = __builtin_amdgcn_fdot2(a2, one, __builtin_amdgcn_fdot2(a3, one, 0.f, false), false);
           const float q1 = __builtin_amdgcn_fdot2(a2, a2, __builtin_amdgcn_fdot2(a3, a3, 0.f, false), false);
-          if (gn_straddle && m0 + h * CH + it * RPI + rr >= gn_bnd) { gs[4] += s0; gs[5] += q0; gs[6] += s1; gs[7] += q1; }
-          else { gs[0] += s0; gs[1] += q0; gs[2] += s1; gs[3] += q1; }
+#else                                                            // bf16 build: no 16-bit dot product of this format; fp32 sums of the unpacked values
+          const float f0 = alo(v.x), f1 = ahi(v.x), f2 = alo(v.y), f3 = ahi(v.y), f4 = alo(v.z), f5 = ahi(v.z), f6 = alo(v.w), f7 = ahi(v.w);
+          const float s0 = (f0 + f1) + (f2 + f3), s1 = (f4 + f5) + (f6 + f7);
+          const float q0 = __builtin_fmaf(f0, f0, __builtin_fmaf(f1, f1, __builtin_fmaf(f2, f2, f3 * f3)));
+          const float q1 = __builtin_fmaf(f4, f4, __builtin_fmaf(f5, f5, __builtin_fmaf(f6, f6, f7 * f7)));
+#endif
+          gs[0] += s0; gs[1] += q0; gs[2] += s1; gs[3] += q1;
         }
       }
-#endif
     };
     // EPI_GNBWD: this launch's output is dy, the gradient w.r.t. the OUTPUT of a GroupNorm (+SiLU) whose input x and per-(image, channel)
     // scale / shift / mean are on the tape: the two backward sums per group -- sum dxh and sum dxh (x - mean) with dxh = dy silu'(x scale +
     // shift) scale (gn_partial_kernel<1>'s, with the rstd factor left to the finalize kernel) -- are taken here from the staged tile and the
     // matching rows of x, per wave tile / image / 4-channel quad like the forward sums: the standalone pass over x and dy disappears.
     auto emit_gnb = [&]() {
-      const int mfirst = m0 + h * CH, mlast = mfirst + CH - 1;
-      const int b_first = mfirst >= gn_bnd ? gn_b0 + 1 : gn_b0, b_last = (gn_straddle && mlast >= gn_bnd) ? gn_b0 + 1 : gn_b0;
-      for (int bb = b_first; bb <= b_last; ++bb) {            // (two passes only for the chunk that contains an image boundary)
+      {
+        const int bb = gn_b0;
         float sc[8], sf[8];
         {
           const float* scp = p.gnb_scale + (long long)bb * p.N + ncol;
@@ -299,8 +306,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
           bool ok[HB];
 #pragma unroll
           for (int it = 0; it < HB; ++it) {
-            const int m = mfirst + (g0 + it) * RPI + rr;
-            ok[it] = orows[g0 + it] >= 0 && col_ok && ((m >= gn_bnd ? gn_b0 + 1 : gn_b0) == bb);
+            ok[it] = orows[g0 + it] >= 0 && col_ok;
             xv[it] = *reinterpret_cast<const uint4*>(p.gnb_x + (ok[it] ? (long long)orows[g0 + it] * p.gnb_ldx + ncol : 0ll));
           }
 #pragma unroll
@@ -322,8 +328,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
                 a1[e >> 2] += dxh;
                 a2[e >> 2] = __builtin_fmaf(dxh, xf[e] - mu[e >> 2], a2[e >> 2]);
               }
-              if (bb != gn_b0) { gs[4] += a1[0]; gs[5] += a2[0]; gs[6] += a1[1]; gs[7] += a2[1]; }
-              else { gs[0] += a1[0]; gs[1] += a2[0]; gs[2] += a1[1]; gs[3] += a2[1]; }
+              gs[0] += a1[0]; gs[1] += a2[0]; gs[2] += a1[1]; gs[3] += a2[1];
             }
           }
         }
@@ -510,6 +515,21 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       if constexpr (BITS) { if (bits2 && !(flags & EPI_LRELU2)) emit_bits(); }
       if constexpr (GNS) { if (flags & EPI_GNSTATS) emit_gn(); }
       if constexpr (GNB) { if (flags & EPI_GNBWD) emit_gnb(); }
+      if constexpr (GNS || GNB) {
+        if ((flags & (EPI_GNSTATS | EPI_GNBWD)) && m0 + h * CH < mend) {          // this chunk = slot (m0 + h CH - image start) / 64 of its image
+#pragma unroll
+          for (int o = CPR; o < 64; o <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
+          }
+          if (rr == 0 && col_ok) {
+            const int nq = p.N >> 2, slots = (HqWq + GN_SLOT - 1) / GN_SLOT + 1;
+            float* dst = p.gn_part + (((long long)gn_b0 * slots + (m0 + h * CH - gn_b0 * HqWq) / GN_SLOT) * nq + (ncol >> 2)) * 2;
+            *reinterpret_cast<float4*>(dst) = make_float4(gs[0], gs[1], gs[2], gs[3]);
+          }
+        }
+        gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
+      }
       DMX_LDS_SYNC();
     }
     if (flags & EPI_LRELU2) {
@@ -522,24 +542,6 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
       DMX_LDS_SYNC();
     }
   });
-  if constexpr (GNS || GNB) {
-    if ((flags & (EPI_GNSTATS | EPI_GNBWD)) && m0 < mend) {
-#pragma unroll
-      for (int o = CPR; o < 64; o <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
-      }
-      if (rr == 0 && col_ok) {
-        const int nq = p.N >> 2, slots = (HqWq + GN_TM - 1) / GN_TM + 1, kt = m0 / GN_TM;
-        float* dst = p.gn_part + (((long long)gn_b0 * slots + (kt - (gn_b0 * HqWq) / GN_TM)) * nq + (ncol >> 2)) * 2;
-        *reinterpret_cast<float4*>(dst) = make_float4(gs[0], gs[1], gs[2], gs[3]);
-        if (gn_straddle) {       // the same tile is slot 0 of the next image
-          float* dh = p.gn_part + (((long long)(gn_b0 + 1) * slots) * nq + (ncol >> 2)) * 2;
-          *reinterpret_cast<float4*>(dh) = make_float4(gs[4], gs[5], gs[6], gs[7]);
-        }
-      }
-    }
-  }
 #undef DMX_LDS_SYNC
 }
 

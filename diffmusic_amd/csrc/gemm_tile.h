@@ -108,7 +108,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   if (tid < DMX_MAX_TAPS) s_taps[tid] = make_short2(p.tdy[tid], p.tdx[tid]);
   float2* s_ln = reinterpret_cast<float2*>(smem + 2 * STAGE + DMX_MAX_TAPS * 4);      // LNF: (mean, rstd) of the BM rows, then BN weight row sums
   float* s_cs = reinterpret_cast<float*>(smem + 2 * STAGE + DMX_MAX_TAPS * 4 + BM * 8);
-  if constexpr (LNF) ln_prologue<BM, BN, NT>(p, tm * BM, tn * BN, s_ln, s_cs);
+  int m0t = tm * BM, mlim = p.M;          // first GEMM row of this tile / first row it does not own
+  if constexpr (EM == 5 || EM == 6) {     // GroupNorm partial sums: image-aligned M tiling where a wave tile would straddle images (gemm_glds_kernel)
+    const int P = p.Hq * p.Wq;
+    if (P % TM != 0) {
+      const int tpi = (P + BM - 1) / BM, b = tm / tpi;
+      m0t = b * P + (tm - b * tpi) * BM;
+      mlim = (b + 1) * P;
+    }
+  }
+  if constexpr (LNF) ln_prologue<BM, BN, NT>(p, m0t, tn * BN, s_ln, s_cs);
 
   // ---- per-thread gather bookkeeping (rows are fixed over the K loop)
   const int cc = tid & 7, r0 = tid >> 3;
@@ -118,8 +127,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   int a_iy[A_PER], a_ix[A_PER];
 #pragma unroll
   for (int i = 0; i < A_PER; ++i) {
-    const int m = tm * BM + r0 + i * ROWS_PER_PASS;
-    if (m < p.M) {
+    const int m = m0t + r0 + i * ROWS_PER_PASS;
+    if (m < mlim) {
       const int b = m / HqWq, rem = m - b * HqWq;
       const int qy = rem / p.Wq, qx = rem - qy * p.Wq;
       a_base[i] = Ab + (long long)b * p.Hi * p.Wi * p.lda;
@@ -233,12 +242,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmDesc p) {
   if constexpr (LNF) ln_apply<FM, FN, BN>(acc, s_ln, s_cs, wm * TM, wn * TN, lr, lq);
 
   if ((p.flags & EPI_F32OUT) || ((p.N | p.ldc | p.ldr | p.ldx | p.ldc2) & 7)) {     // direct path: fp32 out or rows not 16-B granular
-    gemm_epilogue<FM, FN>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
+    gemm_epilogue<FM, FN>(p, acc, m0t + wm * TM, tn * BN + wn * TN, lr, lq, coff, HqWq);
   } else {
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN, EM>(p, acc, tm * BM + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, EM>(p, acc, m0t + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES, mlim);
   }
 }
 
@@ -262,7 +271,9 @@ __device__ unsigned long long g_gemm_stamps[8192 * 6];
 #endif
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EM, bool LNF = false>
-__device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn) {
+__device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const int m0, const int tn, const int mlim) {
+  // mlim: first GEMM row this tile does NOT own (p.M, or the end of the tile's image under the image-aligned tiling of the
+  // GroupNorm-statistics instantiations): rows from there on are neither fetched nor stored
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;
   constexpr int FM = TM / 16, FN = TN / 16;
@@ -313,7 +324,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
       const int m = m0 + (i * NW + wave) * 8 + lrow;
       r_mask[i] = 0u; a_lin[i] = 0u;
       r_iy[i] = -(1 << 20); r_ix[i] = 0;
-      if (m < p.M) {
+      if (m < mlim) {
         int b = 0, qy = 0, qx = m;                                   // plain GEMM rows (one "image" of M x 1 pixels): no divisions
         // (hoisting the divisions out -- image / pixel of the tile's first row once, rows by offset -- leaves the 3.3-6 us a workgroup
         //  spends before its first MFMA unchanged: that time is the latency of the ring's first loads; scripts/dev/r03_gemm_stamps.py)
@@ -581,7 +592,7 @@ __device__ __forceinline__ void glds_tile(const GemmDesc& p, char* smem, const i
     constexpr int EPI_CH = EpiChunk<FM>::CH;
     constexpr int EPI_WAVE_BYTES = EPI_CH * (FN * 32 + 16) + EPI_CH * 12;
     static_assert(EPI_WAVE_BYTES * WM * WN <= 2 * (BM + BN) * 128, "epilogue staging does not fit the stage buffers");
-    gemm_epilogue_lds<FM, FN, EM>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES);
+    gemm_epilogue_lds<FM, FN, EM>(p, acc, m0 + wm * TM, tn * BN + wn * TN, lane, coff, HqWq, smem + wave * EPI_WAVE_BYTES, mlim);
   }
 #ifdef DMX_GEMM_STAMPS
   DMX_GSTAMP(3);                                         // every store of the epilogue issued ...
@@ -613,7 +624,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_glds_kernel(const GemmDesc p
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tiles_n = (p.N + BN - 1) / BN;
   const int bid = xcd_remap(blockIdx.x);
-  glds_tile<BM, BN, WM, WN, NSTAGE, EM, LNF>(p, smem, (bid / tiles_n) * BM, bid % tiles_n);
+  int m0 = (bid / tiles_n) * BM, mlim = p.M;
+  if constexpr (EM == 5 || EM == 6) {
+    // GroupNorm partial sums are kept per wave tile and image.  Where the rows of an image are no multiple of the wave tile's, a flat M
+    // tiling would cut every image's slots at another place -- a clip's statistics would depend on its position in the batch in the last
+    // bits -- so the M tiles restart at every image (the image's last tile is partial; rows past its end are masked like rows past M)
+    const int P = p.Hq * p.Wq;
+    if (P % (BM / WM) != 0) {
+      const int tpi = (P + BM - 1) / BM, tm = bid / tiles_n, b = tm / tpi;
+      m0 = b * P + (tm - b * tpi) * BM;
+      mlim = (b + 1) * P;
+    }
+  }
+  glds_tile<BM, BN, WM, WN, NSTAGE, EM, LNF>(p, smem, m0, bid % tiles_n, mlim);
 }
 
 template <int BM, int BN, int WM, int WN, int NSTAGE, int EM, bool LNF = false>
@@ -627,7 +650,11 @@ int launch_glds_t(const GemmDesc& d, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
-  const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  if constexpr (EM == 5 || EM == 6) {                  // image-aligned M tiling (see gemm_glds_kernel)
+    const int P = d.Hq * d.Wq;
+    if (P % (BM / WM) != 0) tiles = (long long)(d.M / P) * cdiv(P, BM) * cdiv(d.N, BN);
+  }
   dim3 grid((unsigned)tiles, (unsigned)d.Z, (unsigned)(d.ksplit > 1 ? d.ksplit : 1));
   static const bool bias_init = getenv("DMX_NO_BIAS_INIT") == nullptr;
   if (bias_init && (d.flags & EPI_BIAS) && d.bias && !(d.flags & (EPI_MASK | EPI_MASKBITS | EPI_SOFTBWD | EPI_LNFOLD))) {
@@ -650,7 +677,11 @@ int launch_cfg_t(const GemmDesc& d, hipStream_t stream) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     attr_set = true;
   }
-  const long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  long long tiles = (long long)cdiv(d.M, BM) * cdiv(d.N, BN);
+  if constexpr (EM == 5 || EM == 6) {                  // image-aligned M tiling (see gemm_kernel)
+    const int P = d.Hq * d.Wq;
+    if (P % (BM / WM) != 0) tiles = (long long)(d.M / P) * cdiv(P, BM) * cdiv(d.N, BN);
+  }
   dim3 grid((unsigned)tiles, (unsigned)d.Z, 1);
   static const bool bias_init = getenv("DMX_NO_BIAS_INIT") == nullptr;
   if (bias_init && (d.flags & EPI_BIAS) && d.bias && !(d.flags & (EPI_MASK | EPI_MASKBITS | EPI_SOFTBWD | EPI_LNFOLD))) {

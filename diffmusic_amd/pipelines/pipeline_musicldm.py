@@ -46,11 +46,20 @@ class MusicLDMPipeline:
     # ---- construction ---------------------------------------------------------------------
     @classmethod
     def from_pretrained(cls, repo_id, torch_dtype=None, seed=0, unet_config=None, vae_config=None, vocoder_config=None, **kw):
-        """`repo_id` may be a local directory with {unet,vae,vocoder}/*.safetensors in the upstream naming, or
-        "synthetic" (seeded variance-preserving weights of the benchmark architecture; no checkpoint exists offline)."""
-        unet = UNetEngine(unet_config if unet_config is not None else cls.unet_default_config)
-        vae, voc = VaeDecoderEngine(vae_config), HifiGanEngine(vocoder_config)
+        """`repo_id`: a local checkpoint directory in the upstream layout -- {unet,vae,vocoder}/config.json + *.safetensors -- whose
+        config files decide the architecture exactly as the reference's `from_pretrained(repo)` does (run.py:218; translated and checked
+        key by key in diffmusic_amd/checkpoint.py, explicit `*_config` arguments win), or "synthetic" (seeded variance-preserving weights of
+        the benchmark architecture; no checkpoint exists offline)."""
         if os.path.isdir(str(repo_id)):
+            from ..checkpoint import ConfigError, read_configs
+            given = dict(unet=unet_config, vae=vae_config, vocoder=vocoder_config)
+            cfgs = read_configs(repo_id) if any(v is None for v in given.values()) else {}
+            cfgs.update({k: v for k, v in given.items() if v is not None})
+            n_ctx = sum(1 for d in cfgs["unet"].get("attn_cross_dims", [0]) if d)
+            want = sum(1 for d in (cls.unet_default_config or {}).get("attn_cross_dims", [0]) if d)
+            if n_ctx != want:
+                raise ConfigError(f"{repo_id}/unet: a U-Net with {n_ctx} cross-attention context(s), but {cls.__name__} conditions on {want}")
+            unet, vae, voc = UNetEngine(cfgs["unet"]), VaeDecoderEngine(cfgs["vae"]), HifiGanEngine(cfgs["vocoder"])
             from safetensors.torch import load_file
             for eng, sub in ((unet, "unet"), (vae, "vae"), (voc, "vocoder")):
                 files = [f for f in os.listdir(os.path.join(repo_id, sub)) if f.endswith(".safetensors")]
@@ -59,6 +68,8 @@ class MusicLDMPipeline:
                     sd.update(load_file(os.path.join(repo_id, sub, f)))
                 eng.load_state_dict(sd, strict=True)          # fails with the full list of missing / mis-shaped / unknown tensors
         else:
+            unet = UNetEngine(unet_config if unet_config is not None else cls.unet_default_config)
+            vae, voc = VaeDecoderEngine(vae_config), HifiGanEngine(vocoder_config)
             for i, eng in enumerate((unet, vae, voc)):
                 eng.load_state_dict(eng.synth_state_dict(seed=seed + i))
         return cls(vae, unet, voc)

@@ -81,8 +81,8 @@ def _conv1x1_with_gnstats(L, x, w, bias, res, P, cfg):
 def test_groupnorm_from_producer_partial_sums(cfg, B, P, K, Cc, silu):
     """EPI_GNSTATS -> gn_parts_kernel: the GEMM that produces a GroupNorm input writes (sum, sum of squares) per wave tile, image and
     4-channel quad from its epilogue; the GroupNorm combines them (Chan, two sweeps) and normalises WITHOUT a statistics pass.  Every
-    instantiated tile (their wave tiles of 32 ... 160 rows straddle the image boundaries of P = 1003 / 700 at different places),
-    4 / 8 / 20 channels per group, and the classic path on the same tensor as the second reference."""
+    instantiated tile (P = 1003 / 700 are no multiples of their wave tiles of 32 ... 160 rows: the launch tiles M per image, each
+    image's last tile partial), 4 / 8 / 20 channels per group, and the classic path on the same tensor as the second reference."""
     from diffmusic_amd import _lib as L
     g = torch.Generator().manual_seed(cfg * 7 + P)
     G, eps = 32, 1e-5
@@ -163,8 +163,8 @@ def test_groupnorm_parts_over_a_concatenation_and_parity_regions():
 def test_groupnorm_backward_from_producer_partial_sums(cfg, B, P, K, Cc, silu):
     """EPI_GNBWD -> gn_bwd_parts_finalize_kernel: the dgrad launch that produces dy of a GroupNorm(+SiLU) writes the two backward sums
     per wave tile / image / quad from its epilogue (sum dxh, sum dxh (x - mean)); the backward then needs no pass over x and dy for them.
-    Checked against torch autograd of group_norm(+silu) and against the classic path on the same tensors, with image boundaries inside
-    wave tiles (P = 1003 / 700) and 4 / 8 / 20 channels per group."""
+    Checked against torch autograd of group_norm(+silu) and against the classic path on the same tensors, with images that are no
+    multiple of the wave tiles (P = 1003 / 700: image-aligned M tiling) and 4 / 8 / 20 channels per group."""
     from diffmusic_amd import _lib as L
     g = torch.Generator().manual_seed(cfg * 11 + P)
     G, eps = 32, 1e-5
@@ -213,3 +213,84 @@ def test_groupnorm_backward_from_producer_partial_sums(cfg, B, P, K, Cc, silu):
     assert rel(dx_classic, gref) < 2e-3
     assert rel(dx_parts, gref) < 2e-3
     assert rel(dx_parts, dx_classic) < 1e-3
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 19, 11, 12, 3])
+def test_producer_partial_sums_do_not_depend_on_the_batch_position(cfg):
+    """The same image at batch positions 0, 2 and 4 of a launch whose images (P = 1003 pixels) are no multiple of the wave tile's rows:
+    its slots -- and the statistics combined from them -- are bit-identical (image-aligned M tiling of the GroupNorm-statistics launches)."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(cfg)
+    B, P, K, Cc, G, eps = 5, 1003, 64, 256, 32, 1e-5
+    xi = torch.randn(3, P, K, generator=g)
+    x = torch.stack([xi[0], xi[1], xi[0], xi[2], xi[0]]).reshape(B * P, K).to(L.act_dtype()).cuda()
+    w = (torch.randn(Cc, K, generator=g) / K ** 0.5).to(L.act_dtype()).cuda()
+    bias = torch.randn(Cc, generator=g).cuda()
+    ri = (1.5 * torch.randn(3, P, Cc, generator=g) + 0.7)
+    res = torch.stack([ri[0], ri[1], ri[0], ri[2], ri[0]]).reshape(B * P, Cc).to(L.act_dtype()).cuda()
+    out, part, tm = _conv1x1_with_gnstats(L, x, w, bias, res, P, cfg)
+    torch.cuda.synchronize()
+    assert tm > 0 and P % tm != 0
+    o = out.reshape(B, P, Cc)
+    assert torch.equal(o[0], o[2]) and torch.equal(o[0], o[4])
+    slots = (P + tm - 1) // tm + 1
+    pr = part[: B * slots * (Cc // 4) * 2].reshape(B, slots, Cc // 4, 2)[:, : (P + tm - 1) // tm]
+    assert bool(torch.isfinite(pr).all())
+    assert torch.equal(pr[0], pr[2]) and torch.equal(pr[0], pr[4]) and not torch.equal(pr[0], pr[1])
+    gamma, beta = torch.ones(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    y = torch.empty_like(out)
+    stats, scale, shift = torch.empty(B, G, 2, device="cuda"), torch.empty(B, Cc, device="cuda"), torch.empty(B, Cc, device="cuda")
+    L.check(L.lib().dmx_groupnorm_parts_raw(C.c_void_p(out.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(gamma.data_ptr()),
+                                            C.c_void_p(beta.data_ptr()), C.c_void_p(stats.data_ptr()), C.c_void_p(scale.data_ptr()),
+                                            C.c_void_p(shift.data_ptr()), B, P, Cc, G, eps, 1, 1, (C.c_void_p * 1)(part.data_ptr()),
+                                            (C.c_int * 6)(tm, P, Cc // 4, 0, Cc // 4, 0), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gn parts")
+    torch.cuda.synchronize()
+    assert torch.equal(stats[0], stats[2]) and torch.equal(stats[0], stats[4])
+    yy = y.reshape(B, P, Cc)
+    assert torch.equal(yy[0], yy[2]) and torch.equal(yy[0], yy[4])
+
+
+def test_groupnorm_parts_raw_refuses_what_it_cannot_run():
+    """No scratch for the classic pass behind this entry point: channel counts per group that are no multiple of 4 and regions that
+    describe no producer launch are DMX_ERR_SHAPE, not a fault on the device."""
+    from diffmusic_amd import _lib as L
+    B, P, Cc, G = 2, 256, 96, 32                      # 3 channels per group
+    x = torch.zeros(B, P, Cc, dtype=L.act_dtype(), device="cuda")
+    y = torch.empty_like(x)
+    f = lambda *s: torch.zeros(*s, device="cuda")
+    part = f(L.lib().dmx_groupnorm_part_floats(B, P, Cc))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    args = lambda Cc_, G_, geom: (p(x), p(y), p(f(Cc_)), p(f(Cc_)), p(f(B, G_, 2)), p(f(B, Cc_)), p(f(B, Cc_)), B, P, Cc_, G_, 1e-5, 0, 1,
+                                  (C.c_void_p * 1)(part.data_ptr()), (C.c_int * 6)(*geom), st)
+    assert L.lib().dmx_groupnorm_parts_raw(*args(96, 32, (64, P, 24, 0, 24, 0))) != 0
+    assert L.lib().dmx_groupnorm_parts_raw(*args(128, 32, (0, P, 32, 0, 32, 0))) != 0        # tm = 0
+    assert L.lib().dmx_groupnorm_parts_raw(*args(128, 32, (64, 32, 32, 0, 32, 0))) != 0       # P < tm
+    assert L.lib().dmx_groupnorm_parts_raw(*args(128, 32, (64, P, 32, 8, 32, 0))) != 0        # quads past C / 4
+    torch.cuda.synchronize()
+
+
+def test_producer_partial_sums_are_the_same_bits_from_every_statistics_tile():
+    """A slot is a 64-row chunk of a 64-column wave tile, summed in one order by every tile that carries statistics (256 x 256, 256 x 128,
+    512 x 128, 128 x 128 LDS-DMA tiles, the register-staged 128 x 128 tile; other choices are mapped onto these): the partial sums and the
+    statistics combined from them do not depend on the tile the cost model picks for a batch size."""
+    from diffmusic_amd import _lib as L
+    g = torch.Generator().manual_seed(99)
+    B, P, K, Cc = 3, 1003, 128, 256
+    x = torch.randn(B * P, K, generator=g).to(L.act_dtype()).cuda()
+    w = (torch.randn(Cc, K, generator=g) / K ** 0.5).to(L.act_dtype()).cuda()
+    bias = torch.randn(Cc, generator=g).cuda()
+    res = (1.5 * torch.randn(B * P, Cc, generator=g) + 0.7).to(L.act_dtype()).cuda()
+    ref = None
+    for cfg in (1, 2, 19, 11, 18, 3, 7, 10, 12, 6):
+        out, part, tm = _conv1x1_with_gnstats(L, x, w, bias, res, P, cfg)
+        torch.cuda.synchronize()
+        assert tm == 64
+        slots = (P + 63) // 64 + 1
+        pr = part[: B * slots * (Cc // 4) * 2].reshape(B, slots, Cc // 4, 2)[:, : (P + 63) // 64].clone()
+        assert bool(torch.isfinite(pr).all())
+        if ref is None:
+            ref = (out.clone(), pr)
+        else:
+            assert torch.equal(out, ref[0]), f"cfg {cfg}: output differs"
+            assert torch.equal(pr, ref[1]), f"cfg {cfg}: partial sums differ from cfg 1"

@@ -81,3 +81,34 @@ def test_pipeline_shard_two_ranks_bit_equal_to_single_rank(tmp_path, n_clips):
     snr = 10 * np.log10((full.astype(np.float64) ** 2).sum() / max(((full - got[0]).astype(np.float64) ** 2).sum(), 1e-30))
     print(f"sharded over 2 ranks vs one batch of {n_clips}: waveform SNR {snr:.1f} dB")
     assert snr > 30.0
+
+
+def test_bench_rccl_path_at_world_size_one():
+    """The RCCL ("nccl") code path the driver's multi-GPU run takes -- init_process_group(device_id=...), device barrier, max-over-ranks
+    all_reduce, device all_gather of the waveforms -- executed on the one GPU of this box at world size 1 (`--force-dist`)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--backend", "nccl", "--steps", "2", "--warmup", "1",
+           "--settle", "2", "--no-cpu-baseline", "--no-stage-times", "--no-full-trajectory"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["finite"] and d["value"] > 0.0
+    assert "RCCL" in d["after_loop"]["collective"] and d["after_loop"]["gather_world_size"] == 1
+    assert d["after_loop"]["gathered_equals_local"] is True and d["after_loop"]["gather_ms"] > 0.0
+    assert d["config"]["launched_by"] == "bench.py spawn"
+
+
+def test_pipeline_shard_through_rccl_at_world_size_one(tmp_path):
+    """`Pipeline.__call__(shard=True)` under an RCCL process group of one rank: the gathered clips equal the call without torch.distributed."""
+    out = str(tmp_path / "gathered.npy")
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multirank_worker.py"), "3", out, "nccl"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    from tests.multirank_worker import problem, gens
+    pipe, kw = problem(3)
+    ref = np.asarray(pipe(generator=gens(3), **kw).audios)
+    got = np.load(out.replace(".npy", "_rank0.npy"))
+    assert np.array_equal(got, ref)

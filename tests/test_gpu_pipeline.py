@@ -145,3 +145,42 @@ def test_pipeline_accepts_prompt_through_text_frontend():
     pipe.text_frontend = front
     b = pipe(prompt=["soft piano"], generator=torch.Generator().manual_seed(5), **kw).audios
     assert torch.equal(a, b)
+
+
+def test_from_pretrained_directory_with_non_default_architecture(tmp_path):
+    """`from_pretrained(<dir>)` takes the architecture from the checkpoint's config.json files (run.py:218; diffmusic_amd/checkpoint.py): a
+    directory in upstream layout with non-default widths loads and runs, and gives the bits of a pipeline configured by hand."""
+    import json
+    import os
+    from safetensors.torch import save_file
+    from diffmusic_amd import checkpoint as ck, inverse_problem as P
+    from diffmusic_amd.engine import HifiGanEngine, UNetEngine, VaeDecoderEngine
+    from diffmusic_amd.pipelines import get_pipeline
+    from diffmusic_amd.schedulers import get_scheduler
+    from tests.test_checkpoint_config import UNET_MUSICLDM, VAE as VAE_JSON, VOCODER
+    ucfg = dict(UNET_MUSICLDM, block_out_channels=[32, 64, 96, 160])
+    ucfg["cross_attention_dim"] = [32, 64, 96, 160]
+    vcfg = dict(VAE_JSON, block_out_channels=[32, 64, 64])
+    hcfg = dict(VOCODER, upsample_initial_channel=128)
+    engines = {}
+    for sub, cfg, fn, Eng in (("unet", ucfg, ck.unet_config, UNetEngine), ("vae", vcfg, ck.vae_config, VaeDecoderEngine),
+                              ("vocoder", hcfg, ck.vocoder_config, HifiGanEngine)):
+        os.makedirs(tmp_path / sub)
+        with open(tmp_path / sub / "config.json", "w") as fh:
+            json.dump(cfg, fh)
+        eng = Eng(fn(cfg))
+        sd = eng.synth_state_dict(seed=len(engines))
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / sub / "diffusion_pytorch_model.safetensors"))
+        engines[sub] = eng.load_state_dict(sd)
+    pipe = get_pipeline("musicldm").from_pretrained(str(tmp_path)).to("cuda")
+    assert pipe.unet.cfg["block_out_channels"] == [32, 64, 96, 160] and pipe.vocoder.cfg["upsample_initial_channel"] == 128
+    ref = get_pipeline("musicldm")(engines["vae"], engines["unet"], engines["vocoder"]).to("cuda")
+    pe = torch.nn.functional.normalize(torch.randn(1, 512, generator=torch.Generator().manual_seed(1)), dim=-1)
+    outs = []
+    for p in (pipe, ref):
+        p.scheduler = get_scheduler("ddim")(operator=P.IdentityOperator(16000), **SCHED)
+        p.assume_uncond_equals_cond = True
+        outs.append(p(prompt_embeds=pe, audio_length_in_s=0.4, num_inference_steps=3, generator=torch.Generator().manual_seed(0),
+                      show_progress=False).audios)
+    assert outs[0].shape == (1, 6400) and bool((abs(outs[0]) <= 1.0).all()) and float(abs(outs[0]).max()) > 1e-4
+    assert (outs[0] == outs[1]).all()

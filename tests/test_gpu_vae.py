@@ -74,3 +74,32 @@ def test_vae_groupnorm_from_producer_partial_sums(monkeypatch):
         assert _rel(m.cpu(), mref) < 1e-2 and _rel(d.cpu(), gref) < 3e-2
     assert _rel(res["parts"][0], res["classic"][0]) < 3e-3 and _rel(res["parts"][1], res["classic"][1]) < 1e-2
     assert not torch.equal(res["parts"][0], res["classic"][0])          # two different statistics paths really ran
+
+
+def test_vae_is_invariant_to_batch_position_and_composition():
+    """Production-size decoder (default config, 250 x 16 latents: images of 4000 / 16000 / 64000 pixels; 4000 is no multiple of any wave
+    tile's rows).  The GroupNorm partial sums are kept per image-aligned wave tile (gemm_glds_kernel), so what a clip gets -- mel and
+    input-gradient -- must not depend on where it sits in the batch or on its neighbours: the same clip at positions 0, 3 and 7 of
+    batches with different other clips comes back BIT-identical, forward and backward."""
+    from diffmusic_amd.engine import VaeDecoderEngine
+    from diffmusic_amd import _lib as L
+    eng = VaeDecoderEngine()
+    eng.load_state_dict(eng.synth_state_dict(seed=1))
+    g = torch.Generator().manual_seed(77)
+    B, h, w = 8, 250, 16
+    z = torch.randn(B, 8, h, w, generator=g).cuda()
+    dmel = torch.randn(B, 4 * h, 4 * w, generator=g).to(L.act_dtype()).cuda()
+    zs = 1.0 / eng.config.scaling_factor
+
+    def run(order):
+        mel = eng.decode_hip(z[order].contiguous(), z_scale=zs).clone()
+        dz = eng.backward(dmel[order].contiguous(), z_scale=zs).clone()
+        return mel, dz
+    base_mel, base_dz = run(list(range(B)))
+    for order in ([3, 1, 2, 0, 4, 5, 6, 7], [7, 6, 5, 4, 3, 2, 1, 0], [5, 5, 0, 0, 5, 1, 0, 5]):
+        mel, dz = run(order)
+        torch.cuda.synchronize()
+        for pos, k in enumerate(order):
+            assert torch.equal(mel[pos], base_mel[k]), f"mel of clip {k} at position {pos} of {order} differs from position {k}"
+            assert torch.equal(dz[pos], base_dz[k]), f"input-gradient of clip {k} at position {pos} of {order} differs"
+    assert float(base_mel.float().std()) > 0.05 and bool(torch.isfinite(base_dz).all())
