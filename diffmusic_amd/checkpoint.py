@@ -230,8 +230,8 @@ def vocoder_config(cfg, what="vocoder/config.json"):
                upsample_initial_channel=ck.get("upsample_initial_channel", 512), upsample_rates=rates, upsample_kernel_sizes=ks,
                resblock_kernel_sizes=rk, resblock_dilation_sizes=rd, leaky_relu_slope=float(ck.get("leaky_relu_slope", 0.1)))
     uic = out["upsample_initial_channel"]
-    if not isinstance(uic, int) or (isinstance(rates, list) and uic % (2 ** len(rates) * 8)):
-        ck.fail(f"`upsample_initial_channel` = {uic!r}: must halve {len(rates) if isinstance(rates, list) else '?'} times into multiples of 8")
+    if not isinstance(uic, int) or uic <= 0 or (isinstance(rates, list) and uic % (2 ** len(rates))):
+        ck.fail(f"`upsample_initial_channel` = {uic!r}: must halve {len(rates) if isinstance(rates, list) else '?'} times")
     # the mel normalisation in front of the network ((x - mean) / scale): the reference's checkpoints switch it off
     ck.require("normalize_before", (False,), True)
     ck.get("initializer_range", None)

@@ -83,6 +83,40 @@ int dmx_vae_decode_bwd(dmx_model* m, const uint16_t* dmel, float z_scale, float*
   return dmx_vae_bwd_impl(m->impl, dmel, z_scale, dz, ST(stream));
 }
 
+dmx_model* dmx_htsat_create(const dmx_htsat_config* cfg) {
+  Model* impl = dmx_make_htsat(cfg);
+  if (!impl) return nullptr;
+  return new dmx_model{impl};
+}
+int dmx_htsat_feature_dims(dmx_model* m, int* tokens, int* channels) {
+  if (!m || !m->impl || m->impl->kind != DMX_MODEL_HTSAT) { dmx_set_error("wrong model handle"); return DMX_ERR_STATE; }
+  dmx_htsat_dims_impl(m->impl, tokens, channels);
+  return DMX_OK;
+}
+size_t dmx_htsat_workspace_bytes(dmx_model* m, int batch, int frames) {
+  if (!m || !m->impl || m->impl->kind != DMX_MODEL_HTSAT) return 0;
+  return dmx_htsat_ws_impl(m->impl, batch, frames);
+}
+int dmx_htsat_fwd(dmx_model* m, const float* mel, int batch, int frames, float* feat, int keep_state, void* ws, size_t ws_bytes, void* stream) {
+  int rc = check(m, DMX_MODEL_HTSAT);
+  if (rc) return rc;
+  if (!ws) { dmx_set_error("null workspace"); return DMX_ERR_WORKSPACE; }
+  return dmx_htsat_fwd_impl(m->impl, mel, batch, frames, feat, keep_state, ws, ws_bytes, ST(stream));
+}
+int dmx_htsat_bwd(dmx_model* m, const float* dfeat, const float* scale, float* dmel, void* stream) {
+  int rc = check(m, DMX_MODEL_HTSAT);
+  if (rc) return rc;
+  return dmx_htsat_bwd_impl(m->impl, dfeat, scale, dmel, ST(stream));
+}
+int dmx_gram_fwd(const float* F, float* G, int batch, int tokens, int channels, void* stream) {
+  const int rc = dmx_gram_fwd_impl(F, G, batch, tokens, channels, ST(stream));
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("gram: 1 <= tokens <= 96");
+  return rc;
+}
+int dmx_gram_bwd(const float* F, const float* dG, float* dF, int batch, int tokens, int channels, void* stream) {
+  return dmx_gram_bwd_impl(F, dG, dF, batch, tokens, channels, ST(stream));
+}
+
 size_t dmx_unet_workspace_bytes(dmx_model* m, int batch, int h, int w) { return dmx_unet_ws_impl(m->impl, batch, h, w, 0, 0); }
 size_t dmx_unet_workspace_bytes_ctx(dmx_model* m, int batch, int h, int w, int n0, int n1) { return dmx_unet_ws_impl(m->impl, batch, h, w, n0, n1); }
 int dmx_unet_fwd(dmx_model* m, const float* x, const float* t, const float* class_labels, float* eps, int batch, int h, int w,

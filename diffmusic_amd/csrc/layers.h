@@ -106,6 +106,9 @@ ConvLayer make_convT1d(ParamStore& ps, const std::string& prefix, int Ci, int Co
 ConvLayer make_conv2d(ParamStore& ps, const std::string& prefix, int Ci, int Co, int k, int stride, int pad, bool need_bwd);
 ConvLayer make_linear(ParamStore& ps, const std::string& prefix, int Ci, int Co, bool bias, bool need_bwd);
 int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st);
+// n linear layers of equal input width (registered, loaded) packed as ONE layer whose output is their outputs side by side
+// (weights stacked along N, forward and -- when the sources ask for it -- dgrad; biases concatenated): q | k | v in one GEMM
+int pack_linear_stack(ParamStore& ps, ConvLayer& dst, const ConvLayer* const* src, int n, hipStream_t st);
 
 // launches.  Tensors are channels-last with padded channel counts (Cip / Cop).
 // 1-D: in (B, Ti, Cip) -> out (B, To, Cop);  2-D: in (B, Hi, Wi, Cip) -> out (B, Ho, Wo, Cop)

@@ -276,6 +276,42 @@ int pack_layer(ParamStore& ps, ConvLayer& L, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
 }
 
+int pack_linear_stack(ParamStore& ps, ConvLayer& dst, const ConvLayer* const* src, int n, hipStream_t st) {
+  if (n < 1) return DMX_ERR_SHAPE;
+  const int Ci = src[0]->Ci;
+  int Co = 0;
+  bool bias = false, bwd = false;
+  for (int i = 0; i < n; ++i) {
+    if (src[i]->Ci != Ci || src[i]->ntaps() != 1 || src[i]->transposed) { dmx_set_error("stacked projection: linear layers of equal input width"); return DMX_ERR_SHAPE; }
+    Co += src[i]->Co; bias = bias || src[i]->has_bias; bwd = bwd || src[i]->need_bwd;
+  }
+  float *w = nullptr, *b = nullptr;
+  if (hipMalloc(&w, (size_t)Co * Ci * sizeof(float)) != hipSuccess || hipMalloc(&b, (size_t)Co * sizeof(float)) != hipSuccess) {
+    if (w) (void)hipFree(w);
+    return DMX_ERR_PARAM;
+  }
+  (void)hipMemsetAsync(b, 0, (size_t)Co * sizeof(float), st);
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    (void)hipMemcpyAsync(w + off * Ci, ps.dev(src[i]->w_id), (size_t)src[i]->Co * Ci * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (src[i]->has_bias) (void)hipMemcpyAsync(b + off, ps.dev(src[i]->b_id), (size_t)src[i]->Co * sizeof(float), hipMemcpyDeviceToDevice, st);
+    off += src[i]->Co;
+  }
+  dst = ConvLayer();
+  dst.Ci = Ci; dst.Co = Co; dst.Cip = pad8(Ci); dst.Cop = pad8(Co); dst.has_bias = bias; dst.need_bwd = bwd;
+  const std::vector<int> all(1, 0);
+  dst.wf.push_back(pack(ps, w, dst.Cop, Co, 1, dst.Cip, Ci, Ci, 1, 1, all, st));
+  if (bwd) dst.wb = pack(ps, w, dst.Cip, Ci, 1, dst.Cop, Co, 1, Ci, 1, all, st);
+  dst.bias = (float*)ps.dalloc(dst.Cop * sizeof(float));
+  int rc = DMX_OK;
+  if (!dst.wf[0] || (bwd && !dst.wb) || !dst.bias) rc = DMX_ERR_PARAM;
+  else hipLaunchKernelGGL(pad_bias_kernel, dim3(cdiv(dst.Cop, 256)), dim3(256), 0, st, (const float*)b, dst.bias, Co, dst.Cop, 0);
+  (void)hipStreamSynchronize(st);           // model-load time: the temporaries are read by the kernels above
+  (void)hipFree(w); (void)hipFree(b);
+  if (rc == DMX_OK && hipGetLastError() != hipSuccess) rc = DMX_ERR_LAUNCH;
+  return rc;
+}
+
 // ------------------------------------------------------------------------------ descriptors
 static void init_desc(GemmDesc& d, const Epi& e) {
   memset(&d, 0, sizeof(d));

@@ -3,7 +3,7 @@
 #include "layers.h"
 #include "../../include/diffmusic_hip.h"
 
-enum { DMX_MODEL_HIFIGAN = 1, DMX_MODEL_VAE = 2, DMX_MODEL_UNET = 3 };
+enum { DMX_MODEL_HIFIGAN = 1, DMX_MODEL_VAE = 2, DMX_MODEL_UNET = 3, DMX_MODEL_HTSAT = 4 };
 
 struct Model {
   int kind = 0;
@@ -35,3 +35,12 @@ Model* dmx_make_unet(const dmx_unet_config* c);
 size_t dmx_unet_ws_impl(Model* m, int B, int h, int w, int n0, int n1);
 int dmx_unet_fwd_impl(Model* m, const float* x, const float* t, const float* cls, float* eps, int B, int h, int w, void* ws, size_t wsb,
                       hipStream_t st, const float* c0, int n0, const float* c1, int n1, const float* bias1);
+
+// CLAP HTS-AT audio tower (style-guidance operator): forward with tape + input-gradient backward, and the Gram matrix of its features
+Model* dmx_make_htsat(const dmx_htsat_config* c);
+size_t dmx_htsat_ws_impl(Model* m, int B, int frames);
+int dmx_htsat_fwd_impl(Model* m, const float* mel, int B, int frames, float* feat, int keep, void* ws, size_t wsb, hipStream_t st);
+int dmx_htsat_bwd_impl(Model* m, const float* dfeat, const float* scale, float* dmel, hipStream_t st);
+void dmx_htsat_dims_impl(Model* m, int* tokens, int* channels);
+int dmx_gram_fwd_impl(const float* F, float* G, int B, int T, int C, hipStream_t st);
+int dmx_gram_bwd_impl(const float* F, const float* dG, float* dF, int B, int T, int C, hipStream_t st);

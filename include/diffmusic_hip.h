@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DMX_ABI_VERSION 3   /* 2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD / EPI_ROWSTATS / EPI_GNSTATS / EPI_GNBWD: colsum, ln_eps, rowstats_in, rowstats_out, nslots, gn_part, gnb_*) */
+#define DMX_ABI_VERSION 4   /* 4: dmx_htsat_* / dmx_gram_* (CLAP HTS-AT audio tower of the style-guidance operator).  Earlier:  2: dmx_flash_attn_raw takes row-major V (ld = ldv) instead of per-head V^T; GemmDesc grew.  3: GemmDesc grew (EPI_LNFOLD / EPI_ROWSTATS / EPI_GNSTATS / EPI_GNBWD: colsum, ln_eps, rowstats_in, rowstats_out, nslots, gn_part, gnb_*) */
 #define DMX_MAX_STAGES 8
 
 typedef struct dmx_model dmx_model; /* opaque network handle (weights repacked for MFMA) */
@@ -121,6 +121,36 @@ int dmx_unet_fwd_ctx(dmx_model* m, const float* x, const float* t, const float* 
                      const float* ctx1, int n1, const float* bias1, float* eps, int batch, int h, int w, void* ws,
                      size_t ws_bytes, void* stream);
 size_t dmx_unet_workspace_bytes_ctx(dmx_model* m, int batch, int h, int w, int n0, int n1);
+
+/* ---- CLAP HTS-AT audio tower (transformers ClapAudioModel; `StyleGuidanceOperator.transform`, diffmusic/inverse_problem/operator.py:253-271,
+ * config 5 of BASELINE.json): forward with tape and input-gradient backward, hand-written like the three networks above.  Parameter names
+ * are the `ClapAudioModel.state_dict()` keys ("audio_encoder. ..."). ---------------------------------------------------------------------- */
+typedef struct dmx_htsat_config {
+  int spec_size;      /* 256: side of the mel "image" */
+  int num_mel_bins;   /* 64 */
+  int patch_size;     /* 4 (= stride) */
+  int embed_dim;      /* 96 */
+  int window_size;    /* 8 */
+  int num_stages;     /* 4 */
+  int depths[4];      /* 2, 2, 6, 2 */
+  int num_heads[4];   /* 4, 8, 16, 32 (head dim 24 in every stage) */
+  float ln_eps;       /* 1e-5 */
+  float bn_eps;       /* 1e-5 */
+} dmx_htsat_config;
+dmx_model* dmx_htsat_create(const dmx_htsat_config* cfg);
+/* tokens x channels of the feature map dmx_htsat_fwd returns (64 x 768 for the default configuration) */
+int dmx_htsat_feature_dims(dmx_model* m, int* tokens, int* channels);
+size_t dmx_htsat_workspace_bytes(dmx_model* m, int batch, int frames);      /* forward tape + backward scratch */
+/* mel (B, frames, num_mel_bins) fp32 log-mel (ClapFeatureExtractor's input_features without the channel axis), 2 <= frames <= 1024 ->
+ * feat (B, tokens, channels) fp32 = the tower's last_hidden_state (after the final LayerNorm), tokens in grid order.  keep_state != 0
+ * keeps the tape in `ws` for dmx_htsat_bwd.  The first call with a new `frames` builds that length's bicubic tables (allocates). */
+int dmx_htsat_fwd(dmx_model* m, const float* mel, int batch, int frames, float* feat, int keep_state, void* ws, size_t ws_bytes, void* stream);
+/* dfeat (B, tokens, channels) fp32 -> dmel (B, frames, num_mel_bins) fp32, multiplied by scale[b] when scale != NULL (the inverse of a
+ * per-clip normalisation the caller applied to dfeat: the sweep runs in 16 bits). */
+int dmx_htsat_bwd(dmx_model* m, const float* dfeat, const float* scale, float* dmel, void* stream);
+/* Gram matrix of token features: G[b] = F[b]^T F[b] / T, F (B, T, C) fp32 -> G (B, C, C); and dF = F (dG + dG^T) / T */
+int dmx_gram_fwd(const float* F, float* G, int batch, int tokens, int channels, void* stream);
+int dmx_gram_bwd(const float* F, const float* dG, float* dF, int batch, int tokens, int channels, void* stream);
 
 /* ---- STFT / mel measurement path (fp32): replaces torchaudio MelSpectrogram + AmplitudeToDB / MelScale and
  * torch.stft as used by the operators (diffmusic/inverse_problem/operator.py:23-33,143-147,162-170) and the
