@@ -32,6 +32,11 @@ class UNetConfig(C.Structure):
                 ("class_embed_dim", C.c_int), ("num_attn_per_layer", C.c_int), ("attn_cross_dims", C.c_int * 4)]
 
 
+class HtsatConfig(C.Structure):
+    _fields_ = [("spec_size", C.c_int), ("num_mel_bins", C.c_int), ("patch_size", C.c_int), ("embed_dim", C.c_int), ("window_size", C.c_int),
+                ("num_stages", C.c_int), ("depths", C.c_int * 4), ("num_heads", C.c_int * 4), ("ln_eps", C.c_float), ("bn_eps", C.c_float)]
+
+
 class GemmDesc(C.Structure):
     """Mirror of csrc/dmx_common.h::GemmDesc (test hook dmx_gemm_raw only)."""
     _fields_ = [("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("C2", C.c_void_p),
@@ -88,6 +93,14 @@ _SIGS = {
     "dmx_unet_fwd_ctx": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_unet_workspace_bytes_ctx": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dmx_htsat_create": (C.c_void_p, [C.POINTER(HtsatConfig)]),
+    "dmx_htsat_feature_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dmx_htsat_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    "dmx_htsat_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_htsat_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dmx_htsat_tape_raw": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmx_gram_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "dmx_gram_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "dmx_gemm_raw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmx_prof_begin": (None, []),
     "dmx_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -154,7 +167,7 @@ def lib():
     return _lib
 
 
-ABI_VERSION = 3          # include/diffmusic_hip.h DMX_ABI_VERSION
+ABI_VERSION = 4          # include/diffmusic_hip.h DMX_ABI_VERSION
 
 
 def act_dtype():

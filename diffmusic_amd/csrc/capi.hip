@@ -108,6 +108,13 @@ int dmx_htsat_bwd(dmx_model* m, const float* dfeat, const float* scale, float* d
   if (rc) return rc;
   return dmx_htsat_bwd_impl(m->impl, dfeat, scale, dmel, ST(stream));
 }
+size_t dmx_htsat_tape_raw(dmx_model* m, int stage, int block, int which, void* dst, size_t dst_elems, void* stream) {
+  if (!m || !m->impl || m->impl->kind != DMX_MODEL_HTSAT) return 0;
+  const act_t* p = nullptr;
+  const size_t n = dmx_htsat_tape_impl(m->impl, stage, block, which, &p);
+  if (n && dst && dst_elems >= n) (void)hipMemcpyAsync(dst, p, n * sizeof(act_t), hipMemcpyDeviceToDevice, ST(stream));
+  return n;
+}
 int dmx_gram_fwd(const float* F, float* G, int batch, int tokens, int channels, void* stream) {
   const int rc = dmx_gram_fwd_impl(F, G, batch, tokens, channels, ST(stream));
   if (rc == DMX_ERR_SHAPE) dmx_set_error("gram: 1 <= tokens <= 96");

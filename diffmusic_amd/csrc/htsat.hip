@@ -328,39 +328,40 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const act_t* __restric
   sreg[i] = region;
   __syncthreads();
   const int iy = i >> 3, ix = i & 7;
-  float s[WT];
+  // this lane's row of scores / probabilities lives in LDS (sp[i][.], stride 65: lane i and column j hit bank (i + j) mod 64), not in 64
+  // registers: with them the kernel spilled 4.6 KB per lane
   float mx = -3.0e38f;
-#pragma unroll
+#pragma unroll 4
   for (int j = 0; j < WT; ++j) {
     float a = sb[(iy - (j >> 3) + WS - 1) * (2 * WS - 1) + (ix - (j & 7) + WS - 1)];
 #pragma unroll
     for (int d = 0; d < HD; ++d) a = __builtin_fmaf(q[d], sk[j][d], a);
     if (sreg[j] != region) a += -100.f;
-    s[j] = a;
+    sp[i][j] = a;
     mx = fmaxf(mx, a);
   }
   float sum = 0.f;
-#pragma unroll
-  for (int j = 0; j < WT; ++j) { s[j] = __expf(s[j] - mx); sum += s[j]; }
+#pragma unroll 4
+  for (int j = 0; j < WT; ++j) { const float e = __expf(sp[i][j] - mx); sp[i][j] = e; sum += e; }
   const float inv = 1.f / sum;
   // dP[j] = dO . v_j ; delta = sum_j P[j] dP[j] ; dS[j] = P[j] (dP[j] - delta)
   float delta = 0.f;
-#pragma unroll
+#pragma unroll 4
   for (int j = 0; j < WT; ++j) {
-    s[j] *= inv;
+    const float pj = sp[i][j] * inv;
     float a = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) a = __builtin_fmaf(dO[d], sv[j][d], a);
-    sp[i][j] = s[j];
+    sp[i][j] = pj;
     sds[i][j] = a;                                   // dP for now
-    delta = __builtin_fmaf(s[j], a, delta);
+    delta = __builtin_fmaf(pj, a, delta);
   }
   float dq[HD];
 #pragma unroll
   for (int d = 0; d < HD; ++d) dq[d] = 0.f;
-#pragma unroll
+#pragma unroll 4
   for (int j = 0; j < WT; ++j) {
-    const float ds = s[j] * (sds[i][j] - delta);
+    const float ds = sp[i][j] * (sds[i][j] - delta);
     sds[i][j] = ds;
 #pragma unroll
     for (int d = 0; d < HD; ++d) dq[d] = __builtin_fmaf(ds, sk[j][d], dq[d]);
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const act_t* __restric
 // mel (B, frames, 64) fp32 log-mel -> BatchNorm2d over the mel bins (eval) -> bicubic stretch of the time axis to 1024 frames
 // (align_corners = True; taps and weights tabulated on the host, torch's cubic convolution with A = -0.75) -> the 256 x 256 image
 // img[c * 64 + f][tt] = X[c * 256 + tt][f] (ClapAudioEncoder.reshape_mel2img) -> Conv2d(1, E, 4, stride 4) -> LayerNorm(E): one thread per
-// token (E accumulators).  E <= 128.
+// token; a channel of the convolution is 16 multiply-adds of LDS-resident weights and is recomputed where it is needed (statistics, output,
+// backward sums) rather than held in E registers.  E <= 128, a multiple of 8.
 constexpr int EMB_MAX = 128;
 struct EmbedParams {
   const float* mel; const int* tidx; const float* tw; const float* bn_a; const float* bn_b;
@@ -395,111 +397,103 @@ struct EmbedParams {
   int B, frames, E, bins, grid;          // grid = tokens per image side (64), bins = mel bins (64)
   float eps;
 };
-template <int E>
-__device__ __forceinline__ void embed_token(const EmbedParams& p, const float* sW, int b, int tok, float (&pix)[16], float (&pre)[E]) {
+// the 16 BatchNorm'ed, time-stretched pixels of one token (4 mel bins x 4 stretched frames; pix[dy * 4 + dx])
+__device__ __forceinline__ void embed_pixels(const EmbedParams& p, int b, int tok, float (&pix)[16]) {
   const int ty = tok / p.grid, tx = tok - ty * p.grid;
   const int cpb = p.bins / 4;                               // token rows per time chunk
   const int c = ty / cpb, f0 = (ty - c * cpb) * 4;
   const int T = p.grid * 4;                                 // image columns = frames per chunk (256)
+  const float* m = p.mel + (long long)b * p.frames * p.bins + f0;
+  const float4 ba = *reinterpret_cast<const float4*>(p.bn_a + f0), bb = *reinterpret_cast<const float4*>(p.bn_b + f0);
 #pragma unroll
   for (int dx = 0; dx < 4; ++dx) {
     const int tt = c * T + tx * 4 + dx;
     const int4 id = reinterpret_cast<const int4*>(p.tidx)[tt];
     const float4 w = reinterpret_cast<const float4*>(p.tw)[tt];
-    const float* m = p.mel + (long long)b * p.frames * p.bins + f0;
     const float4 a0 = *reinterpret_cast<const float4*>(m + (long long)id.x * p.bins), a1 = *reinterpret_cast<const float4*>(m + (long long)id.y * p.bins);
     const float4 a2 = *reinterpret_cast<const float4*>(m + (long long)id.z * p.bins), a3 = *reinterpret_cast<const float4*>(m + (long long)id.w * p.bins);
-    const float4 ba = *reinterpret_cast<const float4*>(p.bn_a + f0), bb = *reinterpret_cast<const float4*>(p.bn_b + f0);
     pix[0 * 4 + dx] = ba.x * (w.x * a0.x + w.y * a1.x + w.z * a2.x + w.w * a3.x) + bb.x;
     pix[1 * 4 + dx] = ba.y * (w.x * a0.y + w.y * a1.y + w.z * a2.y + w.w * a3.y) + bb.y;
     pix[2 * 4 + dx] = ba.z * (w.x * a0.z + w.y * a1.z + w.z * a2.z + w.w * a3.z) + bb.z;
     pix[3 * 4 + dx] = ba.w * (w.x * a0.w + w.y * a1.w + w.z * a2.w + w.w * a3.w) + bb.w;
   }
-#pragma unroll
-  for (int n = 0; n < E; ++n) {
-    float a = sW[E * 16 + n];
-#pragma unroll
-    for (int k = 0; k < 16; ++k) a = __builtin_fmaf(sW[n * 16 + k], pix[k], a);
-    pre[n] = a;
-  }
 }
-template <int E>
-__global__ __launch_bounds__(128) void embed_fwd_kernel(const EmbedParams p, act_t* __restrict__ tokens) {
-  __shared__ float sW[E * 16 + 3 * E];
+// channel n of the patch convolution (sW: [E][16] weights, then E biases); recomputed wherever it is needed instead of kept in E registers
+__device__ __forceinline__ float embed_chan(const float* sW, int E, int n, const float (&pix)[16]) {
+  float a = sW[E * 16 + n];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) a = __builtin_fmaf(sW[n * 16 + k], pix[k], a);
+  return a;
+}
+__device__ __forceinline__ void embed_load_weights(const EmbedParams& p, float* sW) {
+  const int E = p.E;
   for (int k = threadIdx.x; k < E * 16; k += blockDim.x) sW[k] = p.Wp[k];
   for (int k = threadIdx.x; k < E; k += blockDim.x) { sW[E * 16 + k] = p.bp[k]; sW[E * 17 + k] = p.ln_g[k]; sW[E * 18 + k] = p.ln_b[k]; }
   __syncthreads();
-  const int ntok = p.grid * p.grid;
+}
+__device__ __forceinline__ void embed_stats(const float* sW, int E, const float (&pix)[16], float eps, float& mean, float& rstd) {
+  float s1 = 0.f;
+  for (int n = 0; n < E; ++n) s1 += embed_chan(sW, E, n, pix);
+  mean = s1 / (float)E;
+  float s2 = 0.f;
+  for (int n = 0; n < E; ++n) { const float d = embed_chan(sW, E, n, pix) - mean; s2 = __builtin_fmaf(d, d, s2); }
+  rstd = rsqrtf(s2 / (float)E + eps);
+}
+__global__ __launch_bounds__(128) void embed_fwd_kernel(const EmbedParams p, act_t* __restrict__ tokens) {
+  __shared__ float sW[EMB_MAX * 19];
+  embed_load_weights(p, sW);
+  const int E = p.E, ntok = p.grid * p.grid;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)p.B * ntok) return;
   const int b = (int)(gid / ntok), tok = (int)(gid - (long long)b * ntok);
-  float pix[16], pre[E];
-  embed_token<E>(p, sW, b, tok, pix, pre);
-  float mean = 0.f;
-#pragma unroll
-  for (int n = 0; n < E; ++n) mean += pre[n];
-  mean /= (float)E;
-  float var = 0.f;
-#pragma unroll
-  for (int n = 0; n < E; ++n) { const float d = pre[n] - mean; var += d * d; }
-  const float rstd = rsqrtf(var / (float)E + p.eps);
+  float pix[16];
+  embed_pixels(p, b, tok, pix);
+  float mean, rstd;
+  embed_stats(sW, E, pix, p.eps, mean, rstd);
   act_t* dst = tokens + gid * E;
-#pragma unroll
   for (int k = 0; k < E / 8; ++k) {
     float o[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const int n = k * 8 + e; o[e] = (pre[n] - mean) * rstd * sW[E * 17 + n] + sW[E * 18 + n]; }
+    for (int e = 0; e < 8; ++e) { const int n = k * 8 + e; o[e] = (embed_chan(sW, E, n, pix) - mean) * rstd * sW[E * 17 + n] + sW[E * 18 + n]; }
     reinterpret_cast<uint4*>(dst)[k] = pack8(o);
   }
 }
 // d tokens -> d image (B, 1024, 64) fp32, already multiplied by the BatchNorm scale (every pixel belongs to exactly one token)
-template <int E>
 __global__ __launch_bounds__(128) void embed_bwd_kernel(const EmbedParams p, const act_t* __restrict__ dtok, float* __restrict__ dimg) {
-  __shared__ float sW[E * 16 + 3 * E];
-  for (int k = threadIdx.x; k < E * 16; k += blockDim.x) sW[k] = p.Wp[k];
-  for (int k = threadIdx.x; k < E; k += blockDim.x) { sW[E * 16 + k] = p.bp[k]; sW[E * 17 + k] = p.ln_g[k]; sW[E * 18 + k] = p.ln_b[k]; }
-  __syncthreads();
-  const int ntok = p.grid * p.grid;
+  __shared__ float sW[EMB_MAX * 19];
+  embed_load_weights(p, sW);
+  const int E = p.E, ntok = p.grid * p.grid;
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long long)p.B * ntok) return;
   const int b = (int)(gid / ntok), tok = (int)(gid - (long long)b * ntok);
-  float pix[16], pre[E];
-  embed_token<E>(p, sW, b, tok, pix, pre);
-  float mean = 0.f;
-#pragma unroll
-  for (int n = 0; n < E; ++n) mean += pre[n];
-  mean /= (float)E;
-  float var = 0.f;
-#pragma unroll
-  for (int n = 0; n < E; ++n) { const float d = pre[n] - mean; var += d * d; }
-  const float rstd = rsqrtf(var / (float)E + p.eps);
-  float gsum = 0.f, gxsum = 0.f;
+  float pix[16];
+  embed_pixels(p, b, tok, pix);
+  float mean, rstd;
+  embed_stats(sW, E, pix, p.eps, mean, rstd);
   const act_t* src = dtok + gid * E;
-#pragma unroll
-  for (int k = 0; k < E / 8; ++k) {          // pass 1: pre <- xhat, the two LayerNorm-backward sums (g = d token * gamma is recomputed in pass 2)
+  float gsum = 0.f, gxsum = 0.f;
+  for (int k = 0; k < E / 8; ++k) {          // LayerNorm backward sums: g = d token * gamma
     float d[8];
     unpack8(reinterpret_cast<const uint4*>(src)[k], d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int n = k * 8 + e;
-      const float xh = (pre[n] - mean) * rstd, gg = d[e] * sW[E * 17 + n];
-      pre[n] = xh;
-      gsum += gg; gxsum += gg * xh;
+      const float xh = (embed_chan(sW, E, n, pix) - mean) * rstd, gg = d[e] * sW[E * 17 + n];
+      gsum += gg; gxsum = __builtin_fmaf(gg, xh, gxsum);
     }
   }
   const float mg = gsum / (float)E, mgx = gxsum / (float)E;
   float dp[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) dp[k] = 0.f;
-#pragma unroll
   for (int k = 0; k < E / 8; ++k) {
     float d[8];
     unpack8(reinterpret_cast<const uint4*>(src)[k], d);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int n = k * 8 + e;
-      const float gg = d[e] * sW[E * 17 + n];
-      const float dpre = rstd * (gg - mg - pre[n] * mgx);
+      const float xh = (embed_chan(sW, E, n, pix) - mean) * rstd, gg = d[e] * sW[E * 17 + n];
+      const float dpre = rstd * (gg - mg - xh * mgx);
 #pragma unroll
       for (int q = 0; q < 16; ++q) dp[q] = __builtin_fmaf(sW[n * 16 + q], dpre, dp[q]);
     }
@@ -780,9 +774,7 @@ struct Htsat : Model {
     if (!dry) {
       const EmbedParams p = embed_params(mel, *T);
       const unsigned nb = (unsigned)(((long long)B * N + 127) / 128);
-      if (E == 96) hipLaunchKernelGGL(embed_fwd_kernel<96>, dim3(nb), dim3(128), 0, st, p, cur);
-      else if (E == 128) hipLaunchKernelGGL(embed_fwd_kernel<128>, dim3(nb), dim3(128), 0, st, p, cur);
-      else { dmx_set_error("htsat: patch embedding width %d (96 or 128)", E); return DMX_ERR_SHAPE; }
+      hipLaunchKernelGGL(embed_fwd_kernel, dim3(nb), dim3(128), 0, st, p, cur);
     }
     tape.assign(stages.size(), {});
     t_stage_out.assign(stages.size(), nullptr);
@@ -904,8 +896,7 @@ struct Htsat : Model {
       const EmbedParams p = embed_params(t_mel, *T);
       const long long ntok = (long long)B * grid0 * grid0;
       const unsigned nb = (unsigned)((ntok + 127) / 128);
-      if (cfg.embed_dim == 96) hipLaunchKernelGGL(embed_bwd_kernel<96>, dim3(nb), dim3(128), 0, st, p, d, dimg);
-      else hipLaunchKernelGGL(embed_bwd_kernel<128>, dim3(nb), dim3(128), 0, st, p, d, dimg);
+      hipLaunchKernelGGL(embed_bwd_kernel, dim3(nb), dim3(128), 0, st, p, d, dimg);
       const long long n = (long long)B * frames * cfg.num_mel_bins;
       hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dimg, T->kstart, T->kt, T->kw, scale, dmel, B, frames,
                          cfg.num_mel_bins, Tout);
@@ -914,6 +905,24 @@ struct Htsat : Model {
     A.release(mk_all);
     if (over) { dmx_set_error("htsat backward: workspace too small (size it with dmx_htsat_workspace_bytes)"); return DMX_ERR_WORKSPACE; }
     return hipGetLastError() == hipSuccess ? DMX_OK : DMX_ERR_LAUNCH;
+  }
+
+  // test hook: a tape tensor of the last forward (which: 0 = block input, 1 = q|k|v, 2 = hidden state after attention, 3 = MLP pre-activation;
+  // block == depth of the stage: the stage's output before patch merging).  Returns the element count (16-bit elements), 0 if unknown.
+  size_t tape_tensor(int s, int j, int which, const act_t** p) const {
+    if (!have_tape || s < 0 || s >= (int)stages.size()) return 0;
+    const HtsatStage& S = stages[s];
+    const size_t rows = (size_t)B * S.H * S.W;
+    if (j == (int)S.blocks.size()) { *p = t_stage_out[s]; return rows * S.C; }
+    if (j < 0 || j > (int)S.blocks.size()) return 0;
+    const HtsatBlockTape& t = tape[s][j];
+    switch (which) {
+      case 0: *p = t.x_in; return rows * S.C;
+      case 1: *p = t.qkv; return rows * 3 * S.C;
+      case 2: *p = t.x_mid; return rows * S.C;
+      case 3: *p = t.u; return rows * 4 * S.C;
+      default: return 0;
+    }
   }
 
   // backward scratch on top of the forward's footprint (the forward's dry run only sees the forward)
@@ -937,9 +946,9 @@ struct Htsat : Model {
 };
 
 Model* dmx_make_htsat(const dmx_htsat_config* c) {
-  if (c->num_stages < 1 || c->num_stages > 4 || c->window_size != WS || c->patch_size != 4 || (c->embed_dim != 96 && c->embed_dim != 128) ||
+  if (c->num_stages < 1 || c->num_stages > 4 || c->window_size != WS || c->patch_size != 4 || (c->embed_dim % 8 || c->embed_dim < 8 || c->embed_dim > EMB_MAX) ||
       c->num_mel_bins % 4 || c->spec_size % c->num_mel_bins || c->spec_size % (4 * WS)) {
-    dmx_set_error("htsat: unsupported configuration (window 8, patch 4, embed 96 / 128, <= 4 stages)");
+    dmx_set_error("htsat: unsupported configuration (window 8, patch 4, embed width a multiple of 8 up to 128, <= 4 stages)");
     return nullptr;
   }
   int C = c->embed_dim, side = c->spec_size / 4;
@@ -962,6 +971,9 @@ int dmx_htsat_fwd_impl(Model* m, const float* mel, int B, int frames, float* fea
 }
 int dmx_htsat_bwd_impl(Model* m, const float* dfeat, const float* scale, float* dmel, hipStream_t st) {
   return static_cast<Htsat*>(m)->backward(dfeat, scale, dmel, st);
+}
+size_t dmx_htsat_tape_impl(Model* m, int stage, int block, int which, const act_t** p) {
+  return static_cast<Htsat*>(m)->tape_tensor(stage, block, which, p);
 }
 void dmx_htsat_dims_impl(Model* m, int* tokens, int* channels) {
   Htsat* h = static_cast<Htsat*>(m);

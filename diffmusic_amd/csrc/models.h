@@ -42,5 +42,6 @@ size_t dmx_htsat_ws_impl(Model* m, int B, int frames);
 int dmx_htsat_fwd_impl(Model* m, const float* mel, int B, int frames, float* feat, int keep, void* ws, size_t wsb, hipStream_t st);
 int dmx_htsat_bwd_impl(Model* m, const float* dfeat, const float* scale, float* dmel, hipStream_t st);
 void dmx_htsat_dims_impl(Model* m, int* tokens, int* channels);
+size_t dmx_htsat_tape_impl(Model* m, int stage, int block, int which, const act_t** p);
 int dmx_gram_fwd_impl(const float* F, float* G, int B, int T, int C, hipStream_t st);
 int dmx_gram_bwd_impl(const float* F, const float* dG, float* dF, int B, int T, int C, hipStream_t st);

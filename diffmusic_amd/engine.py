@@ -273,3 +273,84 @@ class UNetEngine(_Engine):
         L.check(lib.dmx_unet_fwd_ctx(self._h, _ptr(x), _ptr(t), _ptr(class_labels), _ptr(c0), n0, _ptr(c1), n1, _ptr(bias1), _ptr(eps),
                                      B, h, w, _ptr(ws), ws.numel(), _stream()), "unet_fwd_ctx")
         return eps
+
+
+HTSAT_DEFAULT = dict(spec_size=256, num_mel_bins=64, patch_size=4, patch_embeds_hidden_size=96, window_size=8, depths=[2, 2, 6, 2],
+                     num_attention_heads=[4, 8, 16, 32], layer_norm_eps=1e-5, batch_norm_eps=1e-5)
+
+
+class HtsatEngine(_Engine):
+    """CLAP HTS-AT audio tower (transformers `ClapAudioModel`) as the style-guidance operator uses it
+    (`StyleGuidanceOperator.transform`, diffmusic/inverse_problem/operator.py:253-271): log-mel features -> token features, and the
+    gradient of a scalar w.r.t. the log-mel features.  `config`: a `ClapAudioConfig` (or a dict of its fields)."""
+    kind = "htsat"
+    allow_unexpected = ("audio_encoder.batch_norm.num_batches_tracked", "audio_encoder.layers.")      # (relative_position_index buffers)
+
+    def __init__(self, config=None, device="cuda"):
+        cfg = dict(HTSAT_DEFAULT)
+        src = config if isinstance(config, dict) or config is None else {k: getattr(config, k) for k in HTSAT_DEFAULT if hasattr(config, k)}
+        cfg.update(src or {})
+        if config is not None and not isinstance(config, dict):
+            unsupported = dict(enable_fusion=False, hidden_act="gelu", qkv_bias=True, enable_patch_layer_norm=True, flatten_patch_embeds=True,
+                               patch_embed_input_channels=1, mlp_ratio=4.0, patch_stride=[4, 4])
+            for k, want in unsupported.items():
+                got = getattr(config, k, want)
+                got = list(got) if isinstance(got, (tuple, list)) else got
+                if got != want:
+                    raise ValueError(f"ClapAudioConfig.{k} = {got!r}: the HIP tower implements {want!r} only")
+        c = L.HtsatConfig()
+        c.spec_size, c.num_mel_bins, c.patch_size = cfg["spec_size"], cfg["num_mel_bins"], cfg["patch_size"]
+        c.embed_dim, c.window_size, c.num_stages = cfg["patch_embeds_hidden_size"], cfg["window_size"], len(cfg["depths"])
+        _fill(c.depths, cfg["depths"])
+        _fill(c.num_heads, cfg["num_attention_heads"])
+        c.ln_eps, c.bn_eps = cfg["layer_norm_eps"], cfg.get("batch_norm_eps", 1e-5)
+        super().__init__(L.lib().dmx_htsat_create(C.byref(c)), cfg, device)
+        t, ch = C.c_int(), C.c_int()
+        L.check(L.lib().dmx_htsat_feature_dims(self._h, C.byref(t), C.byref(ch)), "htsat dims")
+        self.tokens, self.channels = t.value, ch.value
+
+    def load_state_dict(self, sd, strict=False):
+        # buffers of the torch module that carry no parameters of the tower
+        sd = {k: v for k, v in sd.items() if not k.endswith("relative_position_index") and not k.endswith("num_batches_tracked")}
+        return super().load_state_dict(sd, strict=strict)
+
+    def forward(self, mel, keep_state=True):
+        """mel (B, frames, num_mel_bins) fp32 cuda -> token features (B, tokens, channels) fp32 (last_hidden_state, grid order)."""
+        assert mel.dtype == torch.float32 and mel.is_cuda and mel.is_contiguous() and mel.dim() == 3
+        B, frames, _ = mel.shape
+        lib = L.lib()
+        nbytes = lib.dmx_htsat_workspace_bytes(self._h, B, frames)
+        if nbytes == 0:
+            L.check(-1, "htsat workspace")
+        ws = self._workspace(("t", B, frames), nbytes)
+        feat = torch.empty(B, self.tokens, self.channels, dtype=torch.float32, device=mel.device)
+        L.check(lib.dmx_htsat_fwd(self._h, _ptr(mel), B, frames, _ptr(feat), int(keep_state), _ptr(ws), ws.numel(), _stream()), "htsat_fwd")
+        self._shape = (B, frames, mel.shape[2])
+        self._mel = mel                          # the backward pass re-reads the input (its stage is recomputed, not taped)
+        return feat
+
+    def backward(self, dfeat, scale=None):
+        """dfeat (B, tokens, channels) fp32 -> d mel (B, frames, bins) fp32, times scale[b] when given."""
+        B, frames, bins = self._shape
+        assert dfeat.dtype == torch.float32 and dfeat.is_contiguous() and dfeat.shape == (B, self.tokens, self.channels)
+        dmel = torch.empty(B, frames, bins, dtype=torch.float32, device=dfeat.device)
+        L.check(L.lib().dmx_htsat_bwd(self._h, _ptr(dfeat), _ptr(scale), _ptr(dmel), _stream()), "htsat_bwd")
+        return dmel
+
+
+def gram(feat):
+    """G[b] = F[b]^T F[b] / T for token features F (B, T, C) fp32 cuda -> (B, C, C)."""
+    assert feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous()
+    B, T, Cc = feat.shape
+    g = torch.empty(B, Cc, Cc, dtype=torch.float32, device=feat.device)
+    L.check(L.lib().dmx_gram_fwd(_ptr(feat), _ptr(g), B, T, Cc, _stream()), "gram_fwd")
+    return g
+
+
+def gram_backward(feat, dgram):
+    """dF = F (dG + dG^T) / T."""
+    assert dgram.dtype == torch.float32 and dgram.is_contiguous() and feat.is_contiguous()
+    B, T, Cc = feat.shape
+    d = torch.empty_like(feat)
+    L.check(L.lib().dmx_gram_bwd(_ptr(feat), _ptr(dgram), _ptr(d), B, T, Cc, _stream()), "gram_bwd")
+    return d

@@ -471,13 +471,17 @@ class StyleGuidanceOperator(BaseOperator):                # operator.py:253-271 
         transform(audio) = Gram(F) = F F^T / T,   F = CLAP (HTS-AT) audio-encoder token features (B, C, T) of the waveform
 
     computed as: 16 kHz -> 48 kHz sinc-hann polyphase resampling (HIP `dmx_fir_fwd`), CLAP's log-mel front end (48 kHz,
-    n_fft 1024, hop 480, 64 slaney mel bins 0-14 kHz, power dB; HIP `dmx_audio_transform_fwd`), then the HTS-AT tower.
-    The tower is a pretrained third-party network (`transformers.ClapAudioModel`, like the text towers of the prompt front
-    end): it is WRAPPED and differentiated by torch autograd on the GPU, not re-implemented; everything around it (resampler,
-    STFT / mel and their hand-written transposes, Gram loss) is HIP.  Loss = ||G(y) - G(x_hat)||_2 per clip."""
+    n_fft 1024, hop 480, 64 slaney mel bins 0-14 kHz, power dB; HIP `dmx_audio_transform_fwd`), then the HTS-AT tower
+    (`transformers.ClapAudioModel` weights) on the hand-written executor `HtsatEngine` (csrc/htsat.hip: forward with tape and
+    input-gradient backward on the library's GEMM / LayerNorm / window-attention kernels), the Gram matrix and its gradient
+    (`dmx_gram_fwd` / `dmx_gram_bwd`) and the per-clip L2 loss: the whole guidance pair is HIP.  `tower="torch"` runs the wrapped
+    torch module through autograd instead (the round-4 path, kept for A/B measurements only).
+    Loss = ||G(y) - G(x_hat)||_2 per clip."""
 
-    def __init__(self, sample_rate=16000, clap_model=None, noiser=None, device="cuda", seed=0):
-        self.sample_rate, self.noiser = sample_rate, noiser
+    def __init__(self, sample_rate=16000, clap_model=None, noiser=None, device="cuda", seed=0, tower="hip"):
+        if tower not in ("hip", "torch"):
+            raise ValueError("tower: 'hip' (HtsatEngine) or 'torch' (wrapped module, autograd)")
+        self.sample_rate, self.noiser, self.tower = sample_rate, noiser, tower
         self.clap_sr, self.max_samples = 48000, 480000
         kern, self.width, self.orig, self.new = dsp.sinc_resample_kernel(sample_rate, self.clap_sr)
         self._kern_host, self._kern = torch.from_numpy(np.ascontiguousarray(kern)), None
@@ -493,6 +497,10 @@ class StyleGuidanceOperator(BaseOperator):                # operator.py:253-271 
         self.clap = getattr(clap_model, "audio_model", clap_model).to(device).float().eval()
         for p in self.clap.parameters():
             p.requires_grad_(False)
+        self.engine = None
+        if tower == "hip":
+            from ..engine import HtsatEngine
+            self.engine = HtsatEngine(self.clap.config, device=device).load_state_dict(self.clap.state_dict(), strict=True)
 
     def _k(self, device):
         if self._kern is None or self._kern.device != device:
@@ -511,8 +519,25 @@ class StyleGuidanceOperator(BaseOperator):                # operator.py:253-271 
         return mel[:, None], n48
 
     def _gram(self, feats):
+        if self.engine is not None:
+            from ..engine import gram
+            return gram(self.engine.forward(feats[:, 0].contiguous(), keep_state=False))
         f = self.clap(input_features=feats, is_longer=None, return_dict=True).last_hidden_state.flatten(2)   # (B, C, T)
         return torch.bmm(f, f.transpose(1, 2)) / f.shape[2]
+
+    def _tower_guidance(self, feats, ref):
+        """loss[b] = ||ref[b] - Gram(tower(feats[b]))||_2 and d loss / d feats, all HIP: tower forward (tape), Gram, L2 loss + its gradient,
+        Gram transpose, per-clip rescale of the cotangent to the 16-bit range of the tower's backward sweep (undone on its output)."""
+        from ..engine import gram, gram_backward
+        f = self.engine.forward(feats[:, 0].contiguous(), keep_state=True)           # (B, 64, 768) fp32
+        g = gram(f)
+        B = g.shape[0]
+        loss, dg = l2_loss(ref.reshape(ref.shape[0], -1), g.reshape(B, -1))
+        df = gram_backward(f, dg.reshape(g.shape))
+        inv_scale = torch.empty(B, dtype=torch.float32, device=f.device)
+        dfl = df.reshape(B, -1)
+        L.check(L.lib().dmx_grad_normalize(_p(dfl), _p(inv_scale), B, dfl.shape[1], 64.0, _stream()), "grad_normalize")
+        return loss, self.engine.backward(df, scale=inv_scale)[:, None]
 
     @torch.no_grad()
     def transform(self, audio):
@@ -534,11 +559,14 @@ class StyleGuidanceOperator(BaseOperator):                # operator.py:253-271 
             raise ValueError("supervised_space should be either 'wav_form' or 'mel_spectrogram")
         ref = self._ref(measurement, "mel_spectrogram", lambda m: self.transform(m.reshape(m.shape[0], -1)))
         feats, n48 = self._features(y, length)
-        with torch.enable_grad():
-            fg = feats.detach().requires_grad_(True)
-            diff = (ref - self._gram(fg)).flatten(1)
-            loss = torch.linalg.vector_norm(diff, dim=1)                            # per-clip Frobenius norm
-            (dfeat,) = torch.autograd.grad(loss.sum(), fg)
+        if self.engine is not None:
+            loss, dfeat = self._tower_guidance(feats, ref)
+        else:
+            with torch.enable_grad():
+                fg = feats.detach().requires_grad_(True)
+                diff = (ref - self._gram(fg)).flatten(1)
+                loss = torch.linalg.vector_norm(diff, dim=1)                        # per-clip Frobenius norm
+                (dfeat,) = torch.autograd.grad(loss.sum(), fg)
         dx48 = self.frontend.transform_bwd(dfeat[:, 0].contiguous())              # (B, n48)
         dwav = _fir_bwd(dx48, self._k(wav.device), None, length, wav.shape[1], self.orig, self.new, self.width)
         return loss.detach(), dwav

@@ -148,6 +148,10 @@ int dmx_htsat_fwd(dmx_model* m, const float* mel, int batch, int frames, float* 
 /* dfeat (B, tokens, channels) fp32 -> dmel (B, frames, num_mel_bins) fp32, multiplied by scale[b] when scale != NULL (the inverse of a
  * per-clip normalisation the caller applied to dfeat: the sweep runs in 16 bits). */
 int dmx_htsat_bwd(dmx_model* m, const float* dfeat, const float* scale, float* dmel, void* stream);
+/* test hook: copies a tape tensor of the last dmx_htsat_fwd(keep_state = 1) into dst (16-bit activations, token-major): which = 0 block
+ * input, 1 q|k|v, 2 hidden state after attention, 3 MLP pre-activation; block == the stage's depth: the stage output before patch merging.
+ * Returns the tensor's element count (0: no such tensor); copies only when dst_elems is at least that. */
+size_t dmx_htsat_tape_raw(dmx_model* m, int stage, int block, int which, void* dst, size_t dst_elems, void* stream);
 /* Gram matrix of token features: G[b] = F[b]^T F[b] / T, F (B, T, C) fp32 -> G (B, C, C); and dF = F (dG + dG^T) / T */
 int dmx_gram_fwd(const float* F, float* G, int batch, int tokens, int channels, void* stream);
 int dmx_gram_bwd(const float* F, const float* dG, float* dF, int batch, int tokens, int channels, void* stream);

@@ -23,7 +23,7 @@ def test_library_builds_loads_and_exports_all_declared_symbols():
     missing = [n for n in names if not hasattr(h, n)]
     assert not missing, missing
     h.dmx_abi_version.restype = ctypes.c_int
-    assert h.dmx_abi_version() == 3
+    assert h.dmx_abi_version() == 4
     assert h.dmx_act_dtype() in (0, 1)
 
 

@@ -133,6 +133,9 @@ def test_bench_batch_step_matches_per_clip(wl):
         assert worst[k] < (EPS_TOL if k == "eps" else FWD_TOL), (k, rep)
     for k in keys_grad:
         assert worst[k] < GRAD_TOL and worst_cos[k] > GRAD_COS, (k, rep)
+    # the VAE decoder is bit-identical between the bench batch and one clip, forward and backward: its GroupNorm statistics come from
+    # producer partial sums over image-aligned 64-row slots that every statistics-carrying tile sums in the same order (gemm_epilogue.h)
+    assert worst["mel"] == 0.0 and worst["dx0"] == 0.0 and worst["wav"] == 0.0, rep
 
 
 def _snr_db(ref, got):
