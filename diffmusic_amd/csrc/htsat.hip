@@ -569,11 +569,14 @@ __global__ __launch_bounds__(256) void gram_bwd_kernel(const float* __restrict__
       const int t = k >> 5, c = k & 31;
       sf[t][c] = (t0 + t < T && k0 + c < C) ? Fb[(long long)(t0 + t) * C + k0 + c] : 0.f;
     }
-    for (int k = threadIdx.x; k < 32 * 64; k += 256) {
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {           // dG[c'][c]: rows c', coalesced over c
       const int cp = k >> 6, c = k & 63;
-      float v = 0.f;
-      if (k0 + cp < C && c0 + c < C) v = Gb[(long long)(k0 + cp) * C + c0 + c] + Gb[(long long)(c0 + c) * C + k0 + cp];
-      ss[cp][c] = v;
+      ss[cp][c] = (k0 + cp < C && c0 + c < C) ? Gb[(long long)(k0 + cp) * C + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 32 * 64; k += 256) {           // + dG[c][c']: rows c, coalesced over c' (the transposed walk of the first
+      const int c = k >> 5, cp = k & 31;                         // form read one element per 3 KB row: 170 us per launch)
+      if (k0 + cp < C && c0 + c < C) ss[cp][c] += Gb[(long long)(c0 + c) * C + k0 + cp];
     }
     __syncthreads();
 #pragma unroll 4

@@ -308,6 +308,40 @@ __global__ __launch_bounds__(1024) void l2_loss_grad_kernel(const float* __restr
   }
 }
 
+// long rows (the 768 x 768 Gram matrices of the style operator: 590 k elements per clip -- one workgroup per clip took 440 us): per-chunk
+// partial sums parked in the first slots of the clip's dpred row, a finalize launch that adds them in a fixed order, and a gradient launch
+// that overwrites the row (stream order: the partial sums are consumed before the gradient lands on them); no atomics
+constexpr int L2_CHUNK = 8192;
+__global__ __launch_bounds__(256) void l2_partial_kernel(const float* __restrict__ ref, const float* __restrict__ pred, float* __restrict__ dpred,
+                                                         long long n, long long ref_stride) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * L2_CHUNK, i1 = i0 + L2_CHUNK < n ? i0 + L2_CHUNK : n;
+  const float* r = ref + (long long)b * ref_stride;
+  const float* p = pred + (long long)b * n;
+  float s = 0.f;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) { const float d = r[i] - p[i]; s = __builtin_fmaf(d, d, s); }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) dpred[(long long)b * n + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(64) void l2_finalize_kernel(const float* __restrict__ dpred, float* __restrict__ loss, long long n, int nchunk) {
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < nchunk; c += 64) s += dpred[(long long)b * n + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[b] = sqrtf(s);
+}
+__global__ __launch_bounds__(256) void l2_grad_kernel(const float* __restrict__ ref, const float* __restrict__ pred, const float* __restrict__ loss,
+                                                      float* __restrict__ dpred, long long n, long long ref_stride, float gscale) {
+  const int b = blockIdx.y;
+  const long long i0 = (long long)blockIdx.x * L2_CHUNK, i1 = i0 + L2_CHUNK < n ? i0 + L2_CHUNK : n;
+  const float* r = ref + (long long)b * ref_stride;
+  const float* p = pred + (long long)b * n;
+  const float nrm = loss[b], inv = nrm > 0.f ? gscale / nrm : 0.f;
+  float* g = dpred + (long long)b * n;
+  for (long long i = i0 + threadIdx.x; i < i1; i += 256) g[i] = -(r[i] - p[i]) * inv;
+}
+
 // y[b, t] = x[b, t] * mask[t] for t < L, 0 for L <= t < Ly  (row strides xs / ys); mask may be null (copy)
 __global__ void mask_mul_kernel(const float* __restrict__ x, long long xs, const float* __restrict__ mask, float* __restrict__ y,
                                 long long ys, int B, int L, int Ly) {
@@ -436,6 +470,13 @@ int dmx_overlap_add(const float* dframe, float* dwav, long long out_stride, int 
 }
 int dmx_l2_loss_grad(const float* ref, const float* pred, float* loss, float* dpred, int B, long long n, long long ref_stride, float gscale,
                      hipStream_t st) {
+  if (dpred && n >= 8 * L2_CHUNK) {
+    const int nchunk = (int)((n + L2_CHUNK - 1) / L2_CHUNK);
+    hipLaunchKernelGGL(l2_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, ref, pred, dpred, n, ref_stride);
+    hipLaunchKernelGGL(l2_finalize_kernel, dim3(B), dim3(64), 0, st, dpred, loss, n, nchunk);
+    hipLaunchKernelGGL(l2_grad_kernel, dim3(nchunk, B), dim3(256), 0, st, ref, pred, loss, dpred, n, ref_stride, gscale);
+    return CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(l2_loss_grad_kernel, dim3(B), dim3(1024), 0, st, ref, pred, loss, dpred, n, ref_stride, gscale);
   return CHECK_LAUNCH();
 }
