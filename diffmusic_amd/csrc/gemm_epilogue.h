@@ -96,6 +96,9 @@ __device__ __forceinline__ unsigned dmx_pos8(const uint4& v) {
 }
 
 // rows per epilogue chunk: 16 * (largest of 4,3,2,1 that divides FM); 80- and 32-row chunks both measured slower
+#ifndef DMX_GNB_HB
+#define DMX_GNB_HB 4          // rows of the saved GroupNorm input in flight per lane in the backward-sums epilogue (8: one round trip per chunk)
+#endif
 #ifndef DMX_EPI_IB
 #define DMX_EPI_IB 4
 #endif
@@ -299,7 +302,7 @@ __device__ __forceinline__ void gemm_epilogue_lds_impl(const GemmDesc& p, f32x4 
         const float mu[2] = {col_ok ? p.gnb_stats[((long long)bb * ngrp + ncol / p.gnb_cpg) * 2] : 0.f,
                              col_ok ? p.gnb_stats[((long long)bb * ngrp + (ncol + 4) / p.gnb_cpg) * 2] : 0.f};
         // rows of x in flight per lane: a divisor of NIT, at most 4 (8 spilled on the 256 x 256 and 512 x 128 tiles)
-        constexpr int HB = NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : (NIT % 2 == 0 ? 2 : 1));
+        constexpr int HB = DMX_GNB_HB > 4 && NIT % DMX_GNB_HB == 0 ? DMX_GNB_HB : (NIT % 4 == 0 ? 4 : (NIT % 3 == 0 ? 3 : (NIT % 2 == 0 ? 2 : 1)));
 #pragma unroll
         for (int g0 = 0; g0 < NIT; g0 += HB) {
           uint4 xv[HB];

@@ -266,6 +266,44 @@ at::Tensor hifigan_bwd(int64_t model, const at::Tensor& dwav, int64_t frames, in
   return dmel;
 }
 
+// ---- CLAP HTS-AT tower of the style-guidance operator (operator.py:253-271) and the Gram matrix of its token features
+at::Tensor htsat_fwd(int64_t model, const at::Tensor& mel, bool keep_state, at::Tensor ws) {
+  f32_cuda(mel, "mel");
+  TORCH_CHECK(mel.dim() == 3, "mel must be (B, frames, mel bins)");
+  DMX_DEVICE_OF(mel);
+  dmx_model* m = reinterpret_cast<dmx_model*>(model);
+  int tokens = 0, channels = 0;
+  ok(dmx_htsat_feature_dims(m, &tokens, &channels), "htsat_feature_dims");
+  at::Tensor feat = at::empty({mel.size(0), tokens, channels}, mel.options());
+  ok(dmx_htsat_fwd(m, mel.data_ptr<float>(), (int)mel.size(0), (int)mel.size(1), feat.data_ptr<float>(), keep_state, ws.data_ptr(), ws.nbytes(),
+                   cur_stream()), "htsat_fwd");
+  return feat;
+}
+at::Tensor htsat_bwd(int64_t model, const at::Tensor& dfeat, const std::optional<at::Tensor>& scale, int64_t frames, int64_t bins) {
+  f32_cuda(dfeat, "dfeat");
+  DMX_DEVICE_OF(dfeat);
+  if (scale) { f32_cuda(*scale, "scale"); TORCH_CHECK(scale->numel() == dfeat.size(0) && scale->device() == dfeat.device(), "scale must hold one value per clip"); }
+  at::Tensor dmel = at::empty({dfeat.size(0), frames, bins}, dfeat.options());
+  ok(dmx_htsat_bwd(reinterpret_cast<dmx_model*>(model), dfeat.data_ptr<float>(), fp(scale), dmel.data_ptr<float>(), cur_stream()), "htsat_bwd");
+  return dmel;
+}
+at::Tensor gram_fwd(const at::Tensor& feat) {
+  f32_cuda(feat, "feat");
+  TORCH_CHECK(feat.dim() == 3, "feat must be (B, tokens, channels)");
+  DMX_DEVICE_OF(feat);
+  at::Tensor g = at::empty({feat.size(0), feat.size(2), feat.size(2)}, feat.options());
+  ok(dmx_gram_fwd(feat.data_ptr<float>(), g.data_ptr<float>(), (int)feat.size(0), (int)feat.size(1), (int)feat.size(2), cur_stream()), "gram_fwd");
+  return g;
+}
+at::Tensor gram_bwd(const at::Tensor& feat, const at::Tensor& dgram) {
+  f32_cuda(feat, "feat"); f32_cuda(dgram, "dgram");
+  TORCH_CHECK(feat.dim() == 3 && dgram.numel() == feat.size(0) * feat.size(2) * feat.size(2) && dgram.device() == feat.device(), "dgram must be (B, C, C)");
+  DMX_DEVICE_OF(feat);
+  at::Tensor d = at::empty_like(feat);
+  ok(dmx_gram_bwd(feat.data_ptr<float>(), dgram.data_ptr<float>(), d.data_ptr<float>(), (int)feat.size(0), (int)feat.size(1), (int)feat.size(2), cur_stream()), "gram_bwd");
+  return d;
+}
+
 }  // namespace
 
 // the version of include/diffmusic_hip.h this op library was COMPILED against (the loaded libdiffmusic_hip.so reports its own through
@@ -306,4 +344,8 @@ TORCH_LIBRARY(diffmusic_hip, m) {
   m.def("grad_normalize_(Tensor(a!) dwav, float target) -> Tensor", &grad_normalize_);
   m.def("hifigan_fwd(int model, Tensor mel, Tensor(a!) ws) -> Tensor", &hifigan_fwd);
   m.def("hifigan_bwd(int model, Tensor dwav, int frames, int model_in_dim) -> Tensor", &hifigan_bwd);
+  m.def("htsat_fwd(int model, Tensor mel, bool keep_state, Tensor(a!) ws) -> Tensor", &htsat_fwd);
+  m.def("htsat_bwd(int model, Tensor dfeat, Tensor? scale, int frames, int bins) -> Tensor", &htsat_bwd);
+  m.def("gram_fwd(Tensor feat) -> Tensor", &gram_fwd);
+  m.def("gram_bwd(Tensor feat, Tensor dgram) -> Tensor", &gram_bwd);
 }

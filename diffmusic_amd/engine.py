@@ -323,16 +323,20 @@ class HtsatEngine(_Engine):
         if nbytes == 0:
             L.check(-1, "htsat workspace")
         ws = self._workspace(("t", B, frames), nbytes)
-        feat = torch.empty(B, self.tokens, self.channels, dtype=torch.float32, device=mel.device)
-        L.check(lib.dmx_htsat_fwd(self._h, _ptr(mel), B, frames, _ptr(feat), int(keep_state), _ptr(ws), ws.numel(), _stream()), "htsat_fwd")
         self._shape = (B, frames, mel.shape[2])
         self._mel = mel                          # the backward pass re-reads the input (its stage is recomputed, not taped)
+        if ops.enabled():
+            return ops.hip.htsat_fwd(self._h.value, mel, bool(keep_state), ws)
+        feat = torch.empty(B, self.tokens, self.channels, dtype=torch.float32, device=mel.device)
+        L.check(lib.dmx_htsat_fwd(self._h, _ptr(mel), B, frames, _ptr(feat), int(keep_state), _ptr(ws), ws.numel(), _stream()), "htsat_fwd")
         return feat
 
     def backward(self, dfeat, scale=None):
         """dfeat (B, tokens, channels) fp32 -> d mel (B, frames, bins) fp32, times scale[b] when given."""
         B, frames, bins = self._shape
         assert dfeat.dtype == torch.float32 and dfeat.is_contiguous() and dfeat.shape == (B, self.tokens, self.channels)
+        if ops.enabled():
+            return ops.hip.htsat_bwd(self._h.value, dfeat, scale, frames, bins)
         dmel = torch.empty(B, frames, bins, dtype=torch.float32, device=dfeat.device)
         L.check(L.lib().dmx_htsat_bwd(self._h, _ptr(dfeat), _ptr(scale), _ptr(dmel), _stream()), "htsat_bwd")
         return dmel
@@ -342,6 +346,8 @@ def gram(feat):
     """G[b] = F[b]^T F[b] / T for token features F (B, T, C) fp32 cuda -> (B, C, C)."""
     assert feat.dtype == torch.float32 and feat.is_cuda and feat.is_contiguous()
     B, T, Cc = feat.shape
+    if ops.enabled():
+        return ops.hip.gram_fwd(feat)
     g = torch.empty(B, Cc, Cc, dtype=torch.float32, device=feat.device)
     L.check(L.lib().dmx_gram_fwd(_ptr(feat), _ptr(g), B, T, Cc, _stream()), "gram_fwd")
     return g
@@ -351,6 +357,8 @@ def gram_backward(feat, dgram):
     """dF = F (dG + dG^T) / T."""
     assert dgram.dtype == torch.float32 and dgram.is_contiguous() and feat.is_contiguous()
     B, T, Cc = feat.shape
+    if ops.enabled():
+        return ops.hip.gram_bwd(feat, dgram)
     d = torch.empty_like(feat)
     L.check(L.lib().dmx_gram_bwd(_ptr(feat), _ptr(dgram), _ptr(d), B, T, Cc, _stream()), "gram_bwd")
     return d

@@ -68,6 +68,9 @@ class SpectralFrontend:
         assert wav.dtype == torch.float32 and wav.is_cuda and wav.stride(1) == 1
         B = wav.shape[0]
         st = self._get_state(B, length, wav.device)
+        self._last = (B, length, power2, to_db, lo, hi)
+        if ops.enabled() and out is None and self.n_mels == 64:
+            return ops.hip.logmel_fwd(self._h.value, wav, st, int(length), bool(power2), bool(to_db), float(lo), float(hi))
         mel = out if out is not None else torch.empty(B, self.frames(length), self.n_mels, dtype=torch.float32, device=wav.device)
         L.check(L.lib().dmx_audio_transform_fwd(self._h, _p(wav), wav.stride(0), _p(mel), _p(st), B, length, int(power2), int(to_db),
                                                 lo, hi, _stream()), "audio_transform_fwd")
@@ -76,6 +79,8 @@ class SpectralFrontend:
 
     def transform_bwd(self, dmel, dwav=None):
         B, length, power2, to_db, lo, hi = self._last
+        if dwav is None and ops.enabled():
+            return ops.hip.logmel_bwd(self._h.value, dmel.contiguous(), self._state, int(length), bool(power2), bool(to_db), float(lo), float(hi))
         if dwav is None:
             dwav = torch.empty(B, length, dtype=torch.float32, device=dmel.device)
         L.check(L.lib().dmx_audio_transform_bwd(self._h, _p(dmel), _p(dwav), dwav.stride(0), _p(self._state), B, length, int(power2),
@@ -111,6 +116,8 @@ class SpectralFrontend:
     def stft_mag(self, wav, length):
         B = wav.shape[0]
         st = self._get_state(B, length, wav.device)
+        if ops.enabled():
+            return ops.hip.stft_mag_fwd(self._h.value, wav, st, int(length))
         mag = torch.empty(B, self.bins, self.frames(length), dtype=torch.float32, device=wav.device)
         L.check(L.lib().dmx_audio_stft_mag(self._h, _p(wav), wav.stride(0), _p(mag), _p(st), B, length, _stream()), "stft_mag")
         return mag
@@ -124,6 +131,8 @@ class SpectralFrontend:
 
     def melscale(self, mag, lo=_NEG, hi=_POS):
         B, _, T = mag.shape
+        if ops.enabled() and self.n_mels == 64:
+            return ops.hip.melscale_fwd(self._h.value, mag.contiguous(), float(lo), float(hi))
         mel = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=mag.device)
         L.check(L.lib().dmx_audio_melscale(self._h, _p(mag.contiguous()), _p(mel), B, T, lo, hi, _stream()), "melscale")
         return mel
@@ -135,6 +144,9 @@ def l2_loss(ref, pred, want_grad=True, gscale=1.0):
     n = pred[0].numel()
     ref = ref.contiguous()
     assert ref[0].numel() == n, (ref.shape, pred.shape)
+    if ops.enabled() and pred.is_contiguous():
+        loss, dpred = ops.hip.l2norm(ref, pred, float(gscale))
+        return loss, (dpred if want_grad else None)
     loss = torch.empty(B, dtype=torch.float32, device=pred.device)
     dpred = torch.empty_like(pred) if want_grad else None
     L.check(L.lib().dmx_l2_loss(_p(ref), 0 if ref.shape[0] == 1 and B > 1 else n, _p(pred), _p(loss), _p(dpred), B, n, gscale,
@@ -367,6 +379,8 @@ class PhaseRetrievalOperator(BaseOperator):               # operator.py:136-171
 
 def _fir_fwd(x, x_len, h, out_len, orig, new, off):
     B = x.shape[0]
+    if ops.enabled():
+        return ops.hip.resample_fwd(x, h, int(x_len), int(out_len), int(orig), int(new), int(off))
     y = torch.empty(B, out_len, dtype=torch.float32, device=x.device)
     L.check(L.lib().dmx_fir_fwd(_p(x), x.stride(0), _p(h), _p(y), out_len, B, x_len, out_len, h.shape[-1], orig, new, off, _stream()),
             "fir_fwd")
@@ -376,6 +390,8 @@ def _fir_fwd(x, x_len, h, out_len, orig, new, off):
 def _fir_bwd(dy, h, h_rev, in_len, full_len, orig, new, off):
     """gradient w.r.t. the first in_len samples of a (B, full_len) input; the tail gets zero."""
     B, out_len = dy.shape
+    if ops.enabled():
+        return ops.hip.resample_bwd(dy.contiguous(), h, h_rev, int(in_len), int(full_len), int(orig), int(new), int(off))
     d = torch.zeros(B, full_len, dtype=torch.float32, device=dy.device)
     L.check(L.lib().dmx_fir_bwd(_p(dy), out_len, _p(h), _p(h_rev), _p(d), full_len, B, in_len, out_len, h.shape[-1], orig, new, off,
                                 _stream()), "fir_bwd")

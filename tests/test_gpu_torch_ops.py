@@ -42,10 +42,12 @@ def test_scheduler_ops_equal_ctypes_path():
     assert torch.equal(h.randn_philox(list(shp), [1, 2, 3], 5, torch.device("cuda")), randn_philox(shp, [1, 2, 3], 5, "cuda"))
 
 
-def test_measurement_ops_equal_facade():
+def test_measurement_ops_equal_facade(monkeypatch):
     from diffmusic_amd import ops, inverse_problem as P
     from diffmusic_amd.inverse_problem.operator import l2_loss
     h = ops.load()
+    monkeypatch.setattr(ops, "USE_TORCH_OPS", False)          # the facade legs below: ctypes binding (their default is the op layer too)
+    assert not ops.enabled()
     g = torch.Generator().manual_seed(1)
     L_ = 16000
     wav = (0.3 * torch.randn(2, L_ + 32, generator=g)).cuda()
@@ -129,6 +131,34 @@ def test_network_ops_through_handles_equal_engines(monkeypatch):
     L.check(L.lib().dmx_grad_normalize(_p(dw2), _p(inv2), 3, 4000, 64.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "gn")
     assert torch.equal(dw, dw2) and torch.equal(inv, inv2)
     assert torch.allclose(dw.abs().amax(dim=1), torch.full((3,), 64.0, device="cuda"), rtol=1e-5)
+
+
+def test_style_operator_and_operator_helpers_equal_between_bindings(monkeypatch):
+    """The style-guidance pair (HIP resampler, CLAP log-mel, HTS-AT tower forward / backward, Gram, L2) and the super-resolution operator's
+    guidance through torch.ops.diffmusic_hip.* (default) and through ctypes: bit-identical loss and waveform gradient."""
+    import bench
+    from diffmusic_amd import ops, inverse_problem as P
+    assert ops.enabled()
+    L_ = 32000
+    y = torch.stack([bench.synth_clip(1, L_), bench.synth_clip(2, L_)]).cuda()
+    wav = torch.cat([0.5 * y + 0.05 * torch.randn(2, L_, generator=torch.Generator().manual_seed(0)).cuda(), torch.zeros(2, 32, device="cuda")], dim=1).contiguous()
+    style = P.StyleGuidanceOperator(16000, noiser=None, device="cuda", seed=3)
+    sr = P.SuperResolutionOperator(16000, 4, noiser=None)
+    res = {}
+    for tag, on in (("ops", True), ("ctypes", False)):
+        monkeypatch.setattr(ops, "USE_TORCH_OPS", on)
+        assert ops.enabled() == on
+        out = []
+        for op in (style, sr):
+            op.reset_cache()
+            meas = op.forward(y)
+            loss, dwav = op.guidance(wav, L_, meas, "mel_spectrogram")
+            out += [loss.clone(), dwav.clone()]
+        res[tag] = out
+    monkeypatch.setattr(ops, "USE_TORCH_OPS", True)
+    for a, b in zip(res["ops"], res["ctypes"]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)
+    assert float(res["ops"][1].abs().max()) > 0.0
 
 
 def test_ops_fall_back_to_ctypes_with_a_warning_when_the_op_library_is_missing(monkeypatch, tmp_path):
