@@ -62,7 +62,8 @@ struct PairCfg {
   static constexpr int SLAB_IT = (SLAB_ROWS * CPR + NT - 1) / NT;
   static constexpr int BITS_IT = PAIR_ROWS * CPR / NT;
   static constexpr int BITS_BYTES = PAIR_ROWS * CPR;
-  static constexpr int LDS_BYTES = SLAB_BYTES + NS * TILE + BITS_BYTES;
+  static constexpr int BIAS_BYTES = 2 * C * 4;     // both stages' channel biases (fp32): read from LDS wherever a stage needs them (see pair_body)
+  static constexpr int LDS_BYTES = SLAB_BYTES + NS * TILE + BITS_BYTES + BIAS_BYTES;
   static constexpr int MIN_WAVES = C == 32 ? 3 : 2;   // waves per SIMD the register allocation must leave room for (what the LDS footprint allows)
   static_assert(PER >= 1 && PAIR_ROWS * CPR % NT == 0, "tile / thread-count mismatch");
 };
@@ -71,6 +72,39 @@ template <int FN>
 struct PairFrags { frag8_t x[2][4]; frag8_t w[2][FN]; };
 
 #define DMX_PAIR_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+// LDS accesses of the tail between the two stages, as inline asm for the same reason as the fragment reads: while stage B's first weight
+// tiles are in flight (LDS-DMA issued in stage A's last steps) every LDS access the compiler can SEE is preceded by an s_waitcnt vmcnt(0)
+// -- the tail (residual pieces out of the slab, the intermediate written over it, the mask bits, the tape read-back) then started with
+// the full latency of that prefetch exposed.  The asm forms carry their own lgkmcnt waits; the slab and the ring are disjoint.
+#define DMX_LDS_ADDR(p) ((unsigned)(size_t)(__attribute__((address_space(3))) const char*)(p))
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));      // (register-class operands of the asm forms: HIP's uint2 / uint4 are structs)
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pair_lds_w64(const void* p, uint2 v) {
+  const u32x2_t w = {v.x, v.y};
+  asm volatile("ds_write_b64 %0, %1" ::"v"(DMX_LDS_ADDR(p)), "v"(w) : "memory");
+}
+#define DMX_PAIR_DSR64(dst, p) asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(DMX_LDS_ADDR(p)))
+#define DMX_PAIR_DSRU8(dst, p) asm volatile("ds_read_u8 %0, %1" : "=v"(dst) : "v"(DMX_LDS_ADDR(p)))
+__device__ __forceinline__ void pair_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// waits for outstanding LDS reads and ties up to 16 destination registers so that no consumer is scheduled above the wait
+template <typename T>
+__device__ __forceinline__ void pair_tie8(T (&r)[8]) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : : "memory");
+}
+template <typename T>
+__device__ __forceinline__ void pair_tie16(T (&r)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
+                 "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+               :
+               : "memory");
+}
+template <typename T, int N>
+__device__ __forceinline__ void pair_tie(T (&r)[N]) {
+  static_assert(N == 8 || N == 16, "4 row fragments x 2 or 4 column fragments");
+  if constexpr (N == 8) pair_tie8(r); else pair_tie16(r);
+}
 
 // the fragment reads are inline asm (the compiler would otherwise sink them next to their MFMAs and put a vmcnt(0) in front
 // of every LDS read that may alias an LDS-DMA target); this wait ties the registers so no consumer is scheduled above it
@@ -98,6 +132,7 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   char* ring = smem;                                   // 1 KiB-aligned LDS-DMA targets first
   char* slab = smem + NS * TILE;
   unsigned char* s_bits = reinterpret_cast<unsigned char*>(slab + K::SLAB_BYTES);
+  float* s_bias = reinterpret_cast<float*>(slab + K::SLAB_BYTES + K::BITS_BYTES);     // [2][C]: stage A's, stage B's
 
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -189,6 +224,14 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
       if (BPT == 8) d[1] = mb[1];
     }
   }
+  // both stages' channel biases -> LDS, under the slab's round trip: a stage that needs its bias while LDS-DMA or tape stores are in flight
+  // would otherwise wait for ALL of them (vmcnt counts in order) -- stage B's accumulator start used to wait for the tape's store
+  // acknowledgements and the weight prefetch, the backward tail for the prefetch
+  if (tid < 2 * C) {
+    const GemmDesc& d = tid < C ? P.a : P.b;
+    const int ch = tid < C ? tid : tid - C;
+    s_bias[tid] = (!(single && tid < C) && d.bias && (d.flags & (EPI_BIAS | EPI_BIASINIT))) ? d.bias[ch] : 0.f;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   DMX_STAMP(1);
@@ -203,12 +246,16 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   // EPI_BIASINIT: the stage's accumulators start at its channel bias (the bias registers die here, before the K loop)
   auto init_acc = [&](const GemmDesc& d) {
     if (C < 128 && (d.flags & EPI_BIASINIT)) {
+      f32x4 bb[FN];
 #pragma unroll
-      for (int n = 0; n < FN; ++n) {
-        const float4 bb = *reinterpret_cast<const float4*>(d.bias + cg * 64 + n * 16 + lq * 4);
+      for (int n = 0; n < FN; ++n)
+        asm volatile("ds_read_b128 %0, %1" : "=v"(bb[n]) : "v"(DMX_LDS_ADDR(s_bias + (&d == &P.b ? C : 0) + cg * 64 + n * 16 + lq * 4)));
+      if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[0]), "+v"(bb[1]) : : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb[0]), "+v"(bb[1]), "+v"(bb[2]), "+v"(bb[3]) : : "memory");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][n] = f32x4{bb.x, bb.y, bb.z, bb.w};
-      }
+      for (int n = 0; n < FN; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][n] = bb[n];
     } else {
       zero_acc();
     }
@@ -318,6 +365,8 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
   };
 
   uint2 rpre[4 * FN];
+  unsigned tape_bits[2] = {0u, 0u};       // sign bytes of the activated intermediate (forward tape), one per 16-byte chunk this thread read back
+  bool tape_bits_valid = false;
 #pragma unroll
   for (int i = 0; i < 4 * FN; ++i) rpre[i] = make_uint2(0, 0);
   if (!single) {
@@ -331,20 +380,30 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
     // scripts/dev/r03_pair_stamps.py)
     const int fa = P.a.flags;
     float4 abias[FN];
+    {
+      f32x4 ab[FN];
 #pragma unroll
-    for (int n = 0; n < FN; ++n)
-      abias[n] = (fa & EPI_BIAS) ? *reinterpret_cast<const float4*>(P.a.bias + cg * 64 + n * 16 + lq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int n = 0; n < FN; ++n) asm volatile("ds_read_b128 %0, %1" : "=v"(ab[n]) : "v"(DMX_LDS_ADDR(s_bias + cg * 64 + n * 16 + lq * 4)));
+      if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ab[0]), "+v"(ab[1]) : : "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ab[0]), "+v"(ab[1]), "+v"(ab[2]), "+v"(ab[3]) : : "memory");
+#pragma unroll
+      for (int n = 0; n < FN; ++n) abias[n] = (fa & EPI_BIAS) ? make_float4(ab[n][0], ab[n][1], ab[n][2], ab[n][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (P.r_from_slab) {
       // the residual of stage B is the input of stage A: output row r (t = t0 + r) is slab row r + loA + loB; keep this lane's
       // accumulator-layout pieces in registers before the slab is overwritten by the intermediate
+      u32x2_t rp[4 * FN];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int n = 0; n < FN; ++n)
-          rpre[i * FN + n] = *reinterpret_cast<const uint2*>(slab + (rg * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (cg * 64 + n * 16 + lq * 4) * 2);
+          DMX_PAIR_DSR64(rp[i * FN + n], slab + (rg * 64 + i * 16 + lr + P.loA + P.loB) * PITCH + (cg * 64 + n * 16 + lq * 4) * 2);
+      pair_tie(rp);
+#pragma unroll
+      for (int k = 0; k < 4 * FN; ++k) rpre[k] = make_uint2(rp[k][0], rp[k][1]);
       // these rows reach loA + loB rows into the NEXT row group's region, which that group's waves overwrite below:
       // everybody must have taken its residual before anybody stores the intermediate
-      __syncthreads();
+      __builtin_amdgcn_s_barrier();
     }
     DMX_STAMP(6);
     // pointwise tail of stage A, written over the (now dead) input slab; rows outside the clip are the zero padding of stage B
@@ -354,12 +413,22 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
       const int row = rg * 64 + i * 16 + lr;
       const int t = t0 - P.loB + row;
       const bool inside = t >= 0 && t < T;
+      // the mask bytes of this row fragment: FN LDS reads in flight, one wait (asm: see pair_lds_w64)
+      unsigned mbits[FN];
+#pragma unroll
+      for (int n = 0; n < FN; ++n) mbits[n] = 0u;
+      if (fa & (EPI_MASK | EPI_MASKBITS)) {
+#pragma unroll
+        for (int n = 0; n < FN; ++n) DMX_PAIR_DSRU8(mbits[n], s_bits + row * CPR + ((cg * 64 + n * 16 + lq * 4) >> 3));
+        if constexpr (FN == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mbits[0]), "+v"(mbits[1]) : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mbits[0]), "+v"(mbits[1]), "+v"(mbits[2]), "+v"(mbits[3]) : : "memory");
+      }
 #pragma unroll
       for (int n = 0; n < FN; ++n) {
         const int ch = cg * 64 + n * 16 + lq * 4;
         float v[4] = {acc[i][n][0], acc[i][n][1], acc[i][n][2], acc[i][n][3]};
         if (fa & (EPI_MASK | EPI_MASKBITS)) {
-          const unsigned bits = (unsigned)s_bits[row * CPR + (ch >> 3)] >> (ch & 4);
+          const unsigned bits = mbits[n] >> (ch & 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] *= ((bits >> e) & 1u) ? 1.f : mslope;
         }
@@ -372,10 +441,11 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
           for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * aslope;
         }
         if (!inside) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-        *reinterpret_cast<uint2*>(slab + row * PITCH + ch * 2) = make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3]));
+        pair_lds_w64(slab + row * PITCH + ch * 2, make_uint2(pack2a(v[0], v[1]), pack2a(v[2], v[3])));
       }
     }
-    __syncthreads();
+    pair_lds_wait();
+    __builtin_amdgcn_s_barrier();
     DMX_STAMP(7);
     if (fa & EPI_LRELU2) {   // forward: the activated intermediate is part of the tape -> HBM, owned rows only
       // backward only needs its SIGN (the leaky-relu' mask): with EPI_BITS2 one byte per 8 channels goes out (a.B2) and the
@@ -383,20 +453,35 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
       const bool bits = (fa & EPI_BITS2) != 0, full = !P.a_tape_bits_only;
       // all LDS reads first, then all global stores (interleaved, each read waited for the previous iteration's store to complete:
       // the same compiler-inserted vmcnt(0) as above)
-      uint4 tv[K::BITS_IT];
+      u32x4_t tq[K::BITS_IT];
 #pragma unroll
       for (int it = 0; it < K::BITS_IT; ++it) {
         const int c = tid + it * NT, row = c / CPR, piece = c % CPR;
-        tv[it] = *reinterpret_cast<const uint4*>(slab + row * PITCH + piece * 16);
+        asm volatile("ds_read_b128 %0, %1" : "=v"(tq[it]) : "v"(DMX_LDS_ADDR(slab + row * PITCH + piece * 16)));
       }
+      static_assert(K::BITS_IT == 4 || K::BITS_IT == 8, "tape read-back granularity");
+      if constexpr (K::BITS_IT == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]) : : "memory");
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(tq[3]), "+v"(tq[4]), "+v"(tq[5]), "+v"(tq[6]), "+v"(tq[7]) : : "memory");
+      uint4 tv[K::BITS_IT];
+#pragma unroll
+      for (int it = 0; it < K::BITS_IT; ++it) tv[it] = make_uint4(tq[it][0], tq[it][1], tq[it][2], tq[it][3]);
 #pragma unroll
       for (int it = 0; it < K::BITS_IT; ++it) {
         const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
         if (row >= P.loB && row < P.loB + P.BMo && t < T) {
           if (full) *reinterpret_cast<uint4*>(P.a.C2 + ((long long)b * T + t) * C + piece * 8) = tv[it];
-          if (bits) P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)dmx_pos8(tv[it]);
+        }
+        // the sign bytes wait in two registers and leave at the very end of the kernel: stored here, stage B's counted vmcnt waits (the
+        // counter is in order) sat on their acknowledgements
+        if constexpr (C < 128) {
+          if (bits) tape_bits[it >> 2] |= (dmx_pos8(tv[it]) & 0xffu) << (8 * (it & 3));
+        } else {                           // (C = 128 is at its 256 registers: its bytes leave here)
+          if (bits && row >= P.loB && row < P.loB + P.BMo && t < T) P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)dmx_pos8(tv[it]);
         }
       }
+      tape_bits_valid = bits && C < 128;
     }
   }
 
@@ -413,6 +498,14 @@ __device__ __forceinline__ void pair_body(const PairParams& P, char* smem, int b
     const int tend = t0 + P.BMo < T ? t0 + P.BMo : T;
     gemm_epilogue_lds_impl<4, FN, 1>(P.b, acc, mbase + rg * 64, cg * 64, lane, 0, T, slab + wave * EPI_WAVE_BYTES, b * T + tend, rpre,
                                         !single && P.r_from_slab != 0);
+  }
+  if (tape_bits_valid) {
+#pragma unroll
+    for (int it = 0; it < K::BITS_IT; ++it) {
+      const int c = tid + it * NT, row = c / CPR, piece = c % CPR, t = t0 - P.loB + row;
+      if (row >= P.loB && row < P.loB + P.BMo && t < T)
+        P.a.B2[((long long)b * T + t) * P.a.ldb2 + piece] = (unsigned char)((tape_bits[it >> 2] >> (8 * (it & 3))) & 0xffu);
+    }
   }
   DMX_STAMP(5);
 #ifdef DMX_PAIR_STAMPS

@@ -49,10 +49,28 @@ class LaneRunner:
         if unet_priority is None:                         # DMX_LANE_UNET_PRIORITY=0: both streams of equal priority (A/B measurements)
             unet_priority = int(os.environ.get("DMX_LANE_UNET_PRIORITY", "-1"))
         with torch.cuda.device(self.device):
-            # lower number = higher priority; torch clamps to the device's range
-            self.U = torch.cuda.Stream(device=self.device, priority=unet_priority)
-            self.S = torch.cuda.Stream(device=self.device, priority=0)
+            mask = os.environ.get("DMX_LANE_CU_MASK")     # experiment: hex word, repeated over the 8 mask words = the U-Net stream's CUs; the
+            if mask:                                      # sweep stream gets the complement (hipExtStreamCreateWithCUMask)
+                self.U, self.S = self._masked_streams(int(mask, 16))
+            else:
+                # lower number = higher priority; torch clamps to the device's range
+                self.U = torch.cuda.Stream(device=self.device, priority=unet_priority)
+                self.S = torch.cuda.Stream(device=self.device, priority=0)
         self._flags = None
+
+    @staticmethod
+    def _masked_streams(word):
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        out = []
+        for w in (word & 0xffffffff, ~word & 0xffffffff):
+            s = C.c_void_p()
+            arr = (C.c_uint32 * 8)(*([w] * 8))
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(s), C.c_uint32(8), arr)
+            if rc != 0:
+                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+            out.append(torch.cuda.ExternalStream(s.value))
+        return out
 
     def _enqueue_unet(self, lane, i, unet_fn):
         if lane.ev_sweep is not None:
