@@ -139,6 +139,8 @@ _SIGS = {
     "dmx_fir_fwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_void_p]),
     "dmx_fir_bwd": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_int] * 7 + [C.c_void_p]),
     "dmx_sched_pred_x0": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
+    "dmx_sched_pred_x0_ex": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "dmx_sched_step_ex": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "dmx_sched_cfg_combine": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_void_p]),
     "dmx_randn_philox": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.POINTER(C.c_ulonglong), C.c_ulonglong, C.c_void_p]),
     "dmx_sched_step": (C.c_int, [C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int] + [C.c_float] * 5 + [C.c_int, C.c_void_p]),

@@ -180,6 +180,12 @@ int dmx_grad_normalize(float* x, float* inv_scale, int batch, long long n, float
 int dmx_sched_pred_x0(const float* x, const float* eps, float* x0, long long n, float alpha_t, void* stream) {
   return dmx_pred_x0(x, eps, x0, n, sqrtf(alpha_t), sqrtf(1.f - alpha_t), ST(stream));
 }
+int dmx_sched_pred_x0_ex(const float* x, const float* model_output, float* x0, long long n, float alpha_t, int prediction_type, float clip_range,
+                         void* stream) {
+  const int rc = dmx_pred_x0_ex(x, model_output, x0, n, sqrtf(alpha_t), sqrtf(1.f - alpha_t), prediction_type, clip_range, ST(stream));
+  if (rc == DMX_ERR_SHAPE) dmx_set_error("sched_pred_x0_ex: prediction_type 0 (epsilon), 1 (sample) or 2 (v_prediction)");
+  return rc;
+}
 int dmx_sched_cfg_combine(const float* eps2, float* out, long long n, float scale, void* stream) {
   return dmx_cfg_combine(eps2, out, n, scale, ST(stream));
 }
@@ -188,6 +194,12 @@ int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, 
                    float sigma, float rate, float eps_small, int global_norm, void* stream) {
   return dmx_sched_update(mode, x, eps, x0, g0, inv_scale, noise, prev, x0_out, grad_out, batch, n, alpha_t, alpha_prev, sigma, rate,
                           eps_small, global_norm, ST(stream));
+}
+int dmx_sched_step_ex(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
+                      const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
+                      float sigma, float rate, float eps_small, int global_norm, int prediction_type, float clip_range, void* stream) {
+  return dmx_sched_update(mode, x, eps, x0, g0, inv_scale, noise, prev, x0_out, grad_out, batch, n, alpha_t, alpha_prev, sigma, rate,
+                          eps_small, global_norm, ST(stream), prediction_type, clip_range);
 }
 
 }  // extern "C"

@@ -89,7 +89,8 @@ int dmx_stft_mel_bwd(const DmxStftMelTables& t, const float* wav, long long wav_
 
 // ---- sched.hip
 int dmx_pred_x0(const float* x, const float* eps, float* x0, long long n, float sqrt_a, float sqrt_1ma, hipStream_t st);
+int dmx_pred_x0_ex(const float* x, const float* m, float* x0, long long n, float sqrt_a, float sqrt_1ma, int ptype, float clip_r, hipStream_t st);
 int dmx_cfg_combine(const float* eps2, float* out, long long n, float scale, hipStream_t st);
 int dmx_sched_update(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
                      const float* noise, float* prev, float* x0_out, float* grad_out, int B, int n, float alpha_t, float alpha_prev,
-                     float sigma, float rate, float eps_small, int global_norm, hipStream_t st);
+                     float sigma, float rate, float eps_small, int global_norm, hipStream_t st, int ptype = 0, float clip_r = 0.f);

@@ -17,6 +17,22 @@ __global__ void pred_x0_kernel(const float* __restrict__ x, const float* __restr
   if (i < n) x0[i] = (x[i] - sqrt_1ma * eps[i]) / sqrt_a;
 }
 
+// prediction types of the diffusers DDIM parent (DDIMScheduler.step): how pred_original_sample comes out of (x_t, model_output), optionally
+// clipped to [-r, r] (clip_sample).  The guided schedulers differentiate the loss w.r.t. x_t THROUGH x0 (scheduling_dps.py:163-212), so the
+// update kernels need d x0 / d x_t: 1 / sqrt(a) (epsilon), sqrt(a) (v_prediction), 0 (sample), times the clip's pass-through mask.
+enum { P_EPSILON = 0, P_SAMPLE = 1, P_V = 2 };
+__global__ void pred_x0_ex_kernel(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ x0, long long n, float sqrt_a,
+                                  float sqrt_1ma, int ptype, float clip_r) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v;
+  if (ptype == P_EPSILON) v = (x[i] - sqrt_1ma * m[i]) / sqrt_a;
+  else if (ptype == P_SAMPLE) v = m[i];
+  else v = sqrt_a * x[i] - sqrt_1ma * m[i];
+  if (clip_r > 0.f) v = fminf(fmaxf(v, -clip_r), clip_r);
+  x0[i] = v;
+}
+
 struct SchedArgs {
   const float* x;        // sample x_t
   const float* eps;      // model_output
@@ -31,7 +47,17 @@ struct SchedArgs {
   int B;
   float sqrt_a, sqrt_1ma, sqrt_ap, dir_coef, sigma, rate, eps_small, sqrt_1map;
   int global_norm;
+  int ptype;             // prediction type of the parent step (P_EPSILON: the reference's configs)
+  float clip_r;          // > 0: x0 was clipped to [-clip_r, clip_r] -- no gradient flows through a clipped element
 };
+// dL/dx_t of one element from dL/dx0 (already unscaled): the Jacobian of x0(x_t) for the prediction type, zero where x0 sits on the clip bound
+__device__ __forceinline__ float x0_jac(const SchedArgs& a, float g, float x0) {
+  if (a.ptype == P_EPSILON) g = g / a.sqrt_a;
+  else if (a.ptype == P_V) g = g * a.sqrt_a;
+  else g = 0.f;
+  if (a.clip_r > 0.f && !(fabsf(x0) < a.clip_r)) g = 0.f;
+  return g;
+}
 
 enum { M_DDIM = 0, M_DPS = 1, M_MPGD = 2, M_DSG = 3, M_DIFFMUSIC = 4 };
 
@@ -58,7 +84,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
       const long long j = base + i;
       const float x0 = a.x0[j];
       const float e = (a.x[j] - a.sqrt_a * x0) / a.sqrt_1ma;
-      const float g = a.g0[j] * gscale(i) / a.sqrt_a;
+      const float g = x0_jac(a, a.g0[j] * gscale(i), x0);
       float p = a.sqrt_ap * x0 + a.dir_coef * e;
       if (a.noise) p += a.sigma * a.noise[j];
       a.prev[j] = p - a.rate * g;
@@ -80,7 +106,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
     // grad = d(loss/1000)/dx ; r = sqrt(n)*sigma ; d* = -r grad/(|grad|+e) ; mix = s z + rate (d* - s z)
     float s = 0.f;
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
-      const float g = a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[base + i] * gscale(i), a.x0[base + i]) / 1000.f;
       s += g * g;
     }
     const float gnorm = sqrtf(block_sum(s, sh));
@@ -88,7 +114,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
     float m = 0.f;
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
       const long long j = base + i;
-      const float g = a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[j] * gscale(i), a.x0[j]) / 1000.f;
       const float ds = a.sigma * a.noise[j];
       const float mix = ds + a.rate * (-r * g / (gnorm + a.eps_small) - ds);
       m += mix * mix;
@@ -96,7 +122,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
     const float mnorm = sqrtf(block_sum(m, sh));
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
       const long long j = base + i;
-      const float g = a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[j] * gscale(i), a.x0[j]) / 1000.f;
       const float ds = a.sigma * a.noise[j];
       const float mix = ds + a.rate * (-r * g / (gnorm + a.eps_small) - ds);
       const float mean = a.sqrt_ap * a.x0[j] + a.dir_coef * a.eps[j];
@@ -106,7 +132,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
   } else {  // M_DIFFMUSIC: slerp(z, -ghat, rate), ghat = grad/(|grad|+e) * |z|
     float s = 0.f, zz = 0.f;
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
-      const float g = a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[base + i] * gscale(i), a.x0[base + i]) / 1000.f;
       const float z = a.noise[base + i];
       s += g * g; zz += z * z;
     }
@@ -115,7 +141,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
     const float gh = znorm / (gnorm + a.eps_small);      // ghat = g * gh ; x1 = -ghat
     float d = 0.f, x1n = 0.f;
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
-      const float g = a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[base + i] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[base + i] * gscale(i), a.x0[base + i]) / 1000.f;
       const float x1 = -g * gh;
       d += a.noise[base + i] * x1; x1n += x1 * x1;
     }
@@ -130,7 +156,7 @@ __global__ __launch_bounds__(1024) void sched_update_kernel(SchedArgs a) {
     }
     for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
       const long long j = base + i;
-      const float g = a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f);
+      const float g = a.ptype == P_EPSILON && a.clip_r <= 0.f ? a.g0[j] * gscale(i) / (a.sqrt_a * 1000.f) : x0_jac(a, a.g0[j] * gscale(i), a.x0[j]) / 1000.f;
       const float mixed = w0 * a.noise[j] + w1 * (-g * gh);
       const float mean = a.sqrt_ap * a.x0[j] + a.dir_coef * a.eps[j];
       a.prev[j] = mean + a.sigma * mixed;
@@ -157,10 +183,17 @@ int dmx_cfg_combine(const float* eps2, float* out, long long n, float scale, hip
   hipLaunchKernelGGL(cfg_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, eps2, out, n, scale);
   return CHECK_LAUNCH();
 }
+int dmx_pred_x0_ex(const float* x, const float* m, float* x0, long long n, float sqrt_a, float sqrt_1ma, int ptype, float clip_r, hipStream_t st) {
+  if (ptype < P_EPSILON || ptype > P_V) return DMX_ERR_SHAPE;
+  hipLaunchKernelGGL(pred_x0_ex_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, m, x0, n, sqrt_a, sqrt_1ma, ptype, clip_r);
+  return CHECK_LAUNCH();
+}
 int dmx_sched_update(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
                      const float* noise, float* prev, float* x0_out, float* grad_out, int B, int n, float alpha_t, float alpha_prev,
-                     float sigma, float rate, float eps_small, int global_norm, hipStream_t st) {
+                     float sigma, float rate, float eps_small, int global_norm, hipStream_t st, int ptype, float clip_r) {
+  if (ptype < P_EPSILON || ptype > P_V) return DMX_ERR_SHAPE;
   SchedArgs a;
+  a.ptype = ptype; a.clip_r = clip_r;
   a.x = x; a.eps = eps; a.x0 = x0; a.g0 = g0; a.inv_scale = inv_scale; a.noise = noise;
   a.prev = prev; a.x0_out = x0_out; a.grad_out = grad_out; a.n = n; a.B = B;
   a.sqrt_a = sqrtf(alpha_t); a.sqrt_1ma = sqrtf(1.f - alpha_t); a.sqrt_ap = sqrtf(alpha_prev);

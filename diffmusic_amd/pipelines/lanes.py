@@ -46,6 +46,13 @@ class LaneRunner:
 
     def __init__(self, device, unet_priority=None):
         self.device = torch.device(device)
+        # host tensors (the CPU stand-in engines of tests/stubs.py): the same enqueue order and NaN protocol without streams -- only the
+        # host logic is exercised there, the product runs on the GPU
+        self.on_gpu = self.device.type == "cuda"
+        self.U = self.S = None
+        self._flags = None
+        if not self.on_gpu:
+            return
         if unet_priority is None:                         # DMX_LANE_UNET_PRIORITY=0: both streams of equal priority (A/B measurements)
             unet_priority = int(os.environ.get("DMX_LANE_UNET_PRIORITY", "-1"))
         with torch.cuda.device(self.device):
@@ -56,7 +63,6 @@ class LaneRunner:
                 # lower number = higher priority; torch clamps to the device's range
                 self.U = torch.cuda.Stream(device=self.device, priority=unet_priority)
                 self.S = torch.cuda.Stream(device=self.device, priority=0)
-        self._flags = None
 
     @staticmethod
     def _masked_streams(word):
@@ -73,6 +79,9 @@ class LaneRunner:
         return out
 
     def _enqueue_unet(self, lane, i, unet_fn):
+        if not self.on_gpu:
+            lane.eps = unet_fn(lane, i)
+            return
         if lane.ev_sweep is not None:
             self.U.wait_event(lane.ev_sweep)              # this lane's latents of step i - 1
         with torch.cuda.stream(self.U):
@@ -82,6 +91,16 @@ class LaneRunner:
         lane.eps.record_stream(self.S)                    # allocated on U, read by the sweep on S
 
     def _enqueue_sweep(self, lane, i, step_fn, want_flag):
+        if not self.on_gpu:
+            prev, loss = step_fn(lane, i, lane.eps)
+            lane.eps, lane.latents = None, prev
+            lane.losses.append(loss)
+            lane.pending.append(loss)
+            if want_flag:
+                self._flags[lane.index, i] = bool(torch.isnan(torch.cat([l.float().reshape(-1) for l in lane.pending])).any())
+                lane.pending = []
+                lane.nan_events[i] = None
+            return
         self.S.wait_event(lane.ev_unet)
         with torch.cuda.stream(self.S):
             prev, loss = step_fn(lane, i, lane.eps)
@@ -105,18 +124,22 @@ class LaneRunner:
         """Runs all `n_steps` for every lane.  Returns the index of the first step at which a NaN loss was seen by a host check
         (None: the trajectory finished).  NaN checks happen every `nan_check_every` steps and at the last step, per lane, one
         lane-step behind the enqueue front so that the GPU always has the other lane's sweep to run while the host waits."""
-        cur = torch.cuda.current_stream(self.device)
-        self.U.wait_stream(cur)
-        self.S.wait_stream(cur)
         for k, ln in enumerate(lanes):
             ln.index = k
             ln.ev_unet = ln.ev_sweep = None
             ln.losses, ln.pending, ln.nan_events = [], [], {}
-            ln.latents.record_stream(self.U)
-            ln.latents.record_stream(self.S)
-        self._flags = torch.zeros(len(lanes), n_steps, dtype=torch.bool).pin_memory()
-        self._flags_dev = torch.zeros(len(lanes), n_steps, dtype=torch.bool, device=self.device)
-        self.S.wait_stream(cur)                           # (the flag buffer's fill above)
+        if self.on_gpu:
+            cur = torch.cuda.current_stream(self.device)
+            self.U.wait_stream(cur)
+            self.S.wait_stream(cur)
+            for ln in lanes:
+                ln.latents.record_stream(self.U)
+                ln.latents.record_stream(self.S)
+            self._flags = torch.zeros(len(lanes), n_steps, dtype=torch.bool).pin_memory()
+            self._flags_dev = torch.zeros(len(lanes), n_steps, dtype=torch.bool, device=self.device)
+            self.S.wait_stream(cur)                       # (the flag buffer's fill above)
+        else:
+            self._flags = torch.zeros(len(lanes), n_steps, dtype=torch.bool)
         every = max(1, int(nan_check_every))
 
         def due(i):
@@ -130,7 +153,9 @@ class LaneRunner:
             for i in range(n_steps):
                 for ln in lanes:
                     if due(i):
-                        ln.nan_events.pop(i).synchronize()
+                        ev = ln.nan_events.pop(i)
+                        if ev is not None:
+                            ev.synchronize()
                         if bool(self._flags[ln.index, i]):
                             bad_at = i
                             return bad_at
@@ -141,10 +166,11 @@ class LaneRunner:
                     on_step(i)
             return None
         finally:
-            if bad_at is not None:                        # a restart follows: let the work already enqueued drain first
-                self.S.synchronize()
-                self.U.synchronize()
-            cur.wait_stream(self.S)
-            cur.wait_stream(self.U)
-            for ln in lanes:
-                ln.latents.record_stream(cur)
+            if self.on_gpu:
+                if bad_at is not None:                    # a restart follows: let the work already enqueued drain first
+                    self.S.synchronize()
+                    self.U.synchronize()
+                cur.wait_stream(self.S)
+                cur.wait_stream(self.U)
+                for ln in lanes:
+                    ln.latents.record_stream(cur)

@@ -19,6 +19,17 @@ from ..profiling import stage
 from .utils import InverseProblemSchedulerOutput
 
 _MODE = dict(ddim=0, dps=1, mpgd=2, dsg=3, diffmusic=4)
+_PTYPE = dict(epsilon=0, sample=1, v_prediction=2)          # include/diffmusic_hip.h dmx_sched_pred_x0_ex
+
+
+def rescale_zero_terminal_snr(betas):
+    """diffusers `rescale_zero_terminal_snr` (Lin et al. 2023, Algorithm 1): shift / scale sqrt(alpha_bar) so that the last timestep has zero SNR."""
+    alphas_bar_sqrt = torch.cumprod(1.0 - betas, dim=0).sqrt()
+    a0, aT = alphas_bar_sqrt[0].clone(), alphas_bar_sqrt[-1].clone()
+    alphas_bar_sqrt = (alphas_bar_sqrt - aT) * (a0 / (a0 - aT))
+    alphas_bar = alphas_bar_sqrt ** 2
+    alphas = torch.cat([alphas_bar[0:1], alphas_bar[1:] / alphas_bar[:-1]])
+    return 1.0 - alphas
 
 
 def _stream():
@@ -43,13 +54,20 @@ class GuidedDDIMScheduler:
                  thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
                  timestep_spacing="leading", rescale_betas_zero_snr=False, grad_target=64.0, per_clip_norm=True, device_noise=False,
                  *args, **kwargs):
-        if prediction_type != "epsilon" or clip_sample or thresholding or rescale_betas_zero_snr:
-            raise NotImplementedError("only epsilon prediction without clipping/thresholding (the reference's configs) is built")
+        if prediction_type not in _PTYPE:
+            raise ValueError(f"prediction_type given as {prediction_type} must be one of `epsilon`, `sample`, or `v_prediction`")
+        if thresholding:
+            # (dynamic thresholding rescales x0 by a per-sample quantile of |x0| -- Imagen's trick for pixel-space models; no config of the
+            #  reference's latent pipelines selects it: configs/model/*.yaml)
+            raise NotImplementedError("thresholding=True (dynamic thresholding of x0) is not built")
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, trained_betas=trained_betas, clip_sample=clip_sample,
                                       set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset,
                                       prediction_type=prediction_type, thresholding=thresholding,
-                                      timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr)
+                                      timestep_spacing=timestep_spacing, rescale_betas_zero_snr=rescale_betas_zero_snr,
+                                      clip_sample_range=clip_sample_range)
+        self._ptype = _PTYPE[prediction_type]
+        self._clip_r = float(clip_sample_range) if clip_sample else 0.0
         if trained_betas is not None:
             betas = torch.tensor(trained_betas, dtype=torch.float32)
         elif beta_schedule == "linear":
@@ -58,9 +76,13 @@ class GuidedDDIMScheduler:
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         else:
             raise NotImplementedError(f"{beta_schedule} is not implemented")
+        if rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
         self.betas = betas
         self.alphas = 1.0 - betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)            # fp32, host
+        if rescale_betas_zero_snr:
+            self.alphas_cumprod[-1] = 2 ** -24                             # diffusers: "close to 0 without being 0 so first sigma is not inf"
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self._ac = self.alphas_cumprod.numpy()
         self.operator = operator
@@ -155,12 +177,21 @@ class GuidedDDIMScheduler:
                              " `variance_noise` stays `None`.")
         if not sample.is_cuda:
             raise RuntimeError("diffmusic_amd schedulers run on the GPU only (no CPU fallback)")
+        if self._ptype == 1 and self.mode in ("dps", "dsg", "diffmusic"):
+            raise RuntimeError("prediction_type='sample': pred_original_sample = model_output does not depend on the sample, so the gradient of "
+                               "the loss w.r.t. the sample these schedulers take does not exist (the reference's torch.autograd.grad(rec_loss, "
+                               "sample) raises for it, scheduling_dps.py:212)")
         t, a_t, a_p, sigma = self._scalars(timestep, eta)
         x = sample.detach().to(torch.float32).contiguous()
         e = model_output.detach().to(torch.float32).contiguous()
         B, n = x.shape[0], x[0].numel()
         lib = L.lib()
-        if ops.enabled():
+        plain = self._ptype == 0 and self._clip_r == 0.0          # epsilon prediction, no clipping: the reference's configs
+        if not plain:
+            # the DDIM parent's other branches (sample / v_prediction, clip_sample); C-ABI entry points with the type and the clip range
+            x0 = torch.empty_like(x)
+            L.check(lib.dmx_sched_pred_x0_ex(_p(x), _p(e), _p(x0), x.numel(), a_t, self._ptype, self._clip_r, _stream()), "pred_x0_ex")
+        elif ops.enabled():
             x0 = ops.hip.sched_pred_x0(x, e, a_t)                  # torch.ops.diffmusic_hip.* (csrc_torch/torch_ops.cpp)
         else:
             x0 = torch.empty_like(x)
@@ -188,7 +219,14 @@ class GuidedDDIMScheduler:
                     sn = randn_tensor(model_output.shape, generator=generator, device=model_output.device, dtype=model_output.dtype)
                 noise = sn.to(torch.float32).contiguous()
         grad_out = torch.empty_like(x) if self.debug_keep_grad and self.mode != "ddim" else None
-        if ops.enabled() and grad_out is None:
+        if not plain:
+            prev = torch.empty_like(x)
+            x0_out = torch.empty_like(x) if self.mode == "mpgd" else None
+            with stage("sched_update"):
+                L.check(lib.dmx_sched_step_ex(mode, _p(x), _p(e), _p(x0), _p(g0), _p(inv_scale), _p(noise), _p(prev), _p(x0_out),
+                                              _p(grad_out), B, n, a_t, a_p, sigma, float(rate), float(eps), 0 if self.per_clip_norm else 1,
+                                              self._ptype, self._clip_r, _stream()), "sched_step_ex")
+        elif ops.enabled() and grad_out is None:
             with stage("sched_update"):
                 prev, x0_u = ops.hip.sched_update(mode, x, e, x0, g0, inv_scale, noise, a_t, a_p, sigma, float(rate), float(eps),
                                                   not self.per_clip_norm)

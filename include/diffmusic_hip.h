@@ -222,12 +222,22 @@ int dmx_fir_bwd(const float* dout, long long dout_stride, const float* h, const 
 #define DMX_SCHED_DIFFMUSIC 4
 /* x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t) */
 int dmx_sched_pred_x0(const float* x, const float* eps, float* x0, long long n, float alpha_t, void* stream);
+/* the other prediction types of the diffusers DDIM parent every reference scheduler subclasses (scheduling_dps.py:15-61): prediction_type
+ * 0 epsilon (as above), 1 sample (x0 = model_output), 2 v_prediction (x0 = sqrt(a_t) x - sqrt(1-a_t) v); clip_range > 0 clamps x0 to
+ * [-clip_range, clip_range] (clip_sample) */
+int dmx_sched_pred_x0_ex(const float* x, const float* model_output, float* x0, long long n, float alpha_t, int prediction_type, float clip_range,
+                         void* stream);
 /* classifier-free guidance combine on a (2B, ...) U-Net output (pipeline_musicldm.py:706-708) */
 int dmx_sched_cfg_combine(const float* eps2, float* out, long long n, float scale, void* stream);
 /* fused update: g0 = dLoss/dx0 (times 1/inv_scale[b]); see csrc/sched.hip for the per-mode formulas */
 int dmx_sched_step(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
                    const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
                    float sigma, float rate, float eps_small, int global_norm, void* stream);
+/* dmx_sched_step for a parent step of another prediction type / with clip_sample: the gradient w.r.t. x_t passes through x0(x_t), i.e.
+ * d x0 / d x_t = 1 / sqrt(a_t), 0 or sqrt(a_t), and zero where x0 sits on the clip bound */
+int dmx_sched_step_ex(int mode, const float* x, const float* eps, const float* x0, const float* g0, const float* inv_scale,
+                      const float* noise, float* prev, float* x0_out, float* grad_out, int batch, int n, float alpha_t, float alpha_prev,
+                      float sigma, float rate, float eps_small, int global_norm, int prediction_type, float clip_range, void* stream);
 
 /* Device-side N(0,1) noise, Philox4x32-10 + Box-Muller (csrc/rng.hip): optional replacement for the host draw + upload of
  * randn_tensor (diffmusic/torch_utils.py:31-76) that DSG / DiffMusic pay every step (scheduling_dsg.py:215).  out (batch, n)

@@ -31,8 +31,17 @@ class DDIMParent:
                                         dtype=torch.float32) ** 2
         else:
             raise NotImplementedError(beta_schedule)
+        if rescale_betas_zero_snr:
+            # diffusers rescale_zero_terminal_snr: shift / scale sqrt(alpha_bar) to zero terminal SNR, back to betas
+            abs_ = torch.cumprod(1.0 - self.betas, dim=0).sqrt()
+            a0, aT = abs_[0].clone(), abs_[-1].clone()
+            abs_ = (abs_ - aT) * (a0 / (a0 - aT))
+            ab = abs_ ** 2
+            self.betas = 1.0 - torch.cat([ab[0:1], ab[1:] / ab[:-1]])
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        if rescale_betas_zero_snr:
+            self.alphas_cumprod[-1] = 2 ** -24
         self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
@@ -64,8 +73,8 @@ class DDIMParent:
 
     def parent_step(self, model_output, timestep, sample, eta=0.0, generator=None,
                     variance_noise=None):
-        """Returns (prev_sample, pred_original_sample) exactly as DDIMScheduler.step for
-        prediction_type='epsilon', clip_sample=False, thresholding=False.  With eta>0 and
+        """Returns (prev_sample, pred_original_sample) exactly as DDIMScheduler.step (diffusers 0.31.0) for the three
+        prediction types and clip_sample; thresholding=False.  With eta>0 and
         variance_noise None it draws one randn from `generator` (the 'throw-away' draw noted in
         SURVEY.md section 7)."""
         from .rng import randn_tensor
@@ -73,9 +82,18 @@ class DDIMParent:
         a_t = self.alphas_cumprod[timestep]
         a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         b_t = 1 - a_t
-        assert self.cfg["prediction_type"] == "epsilon"
-        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
-        eps = model_output
+        pt = self.cfg["prediction_type"]
+        if pt == "epsilon":
+            x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+            eps = model_output
+        elif pt == "sample":
+            x0 = model_output
+            eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+        elif pt == "v_prediction":
+            x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+            eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+        else:
+            raise ValueError(f"prediction_type given as {pt} must be one of `epsilon`, `sample`, or `v_prediction`")
         if self.cfg["clip_sample"]:
             r = self.cfg["clip_sample_range"]
             x0 = x0.clamp(-r, r)

@@ -186,3 +186,31 @@ def test_checkpoint_manifest_check_lists_everything():
     assert "1 missing, 1 of another shape, 1 unexpected of 3 expected" in msg
     assert "missing     conv_in.bias (128,)" in msg and "expected (640, 640), checkpoint has (640, 1024)" in msg
     assert "unexpected  class_embedding.weight (512, 512)" in msg
+
+
+def test_ddim_parent_variants_host_side():
+    """prediction types / clip_sample / zero-terminal-SNR betas of the diffusers DDIM parent (reference: every scheduler subclasses it,
+    scheduling_dps.py:15-61): accepted and tabulated like the oracle's restatement; thresholding and unknown types are refused."""
+    from diffmusic_amd.schedulers import get_scheduler
+    from diffmusic_amd.schedulers.scheduling_guided import rescale_zero_terminal_snr
+    from oracle import schedulers as OS
+    base = dict(num_train_timesteps=1000, beta_start=0.0015, beta_end=0.0195, beta_schedule="scaled_linear", set_alpha_to_one=False,
+                steps_offset=1, timestep_spacing="trailing")
+    for kw in (dict(prediction_type="v_prediction", clip_sample=False, rescale_betas_zero_snr=True),
+               dict(prediction_type="sample", clip_sample=True, clip_sample_range=2.0)):
+        s = get_scheduler("dps")(operator=None, **base, **kw)
+        r = OS.get_scheduler("dps")(operator=None, **base, **kw)
+        assert torch.equal(s.alphas_cumprod, r.alphas_cumprod) and torch.equal(s.betas, r.betas)
+        s.set_timesteps(200)
+        r.set_timesteps(200)
+        assert s._timesteps_host == [int(t) for t in r.timesteps] and s._timesteps_host[0] == 999
+        assert s.config.prediction_type == kw["prediction_type"]
+    z = get_scheduler("mpgd")(operator=None, **base, prediction_type="v_prediction", clip_sample=False, rescale_betas_zero_snr=True)
+    assert float(z.alphas_cumprod[-1]) == 2.0 ** -24 and float(z.alphas_cumprod[0]) > 0.99
+    b = torch.linspace(0.0015 ** 0.5, 0.0195 ** 0.5, 1000) ** 2
+    ab = torch.cumprod(1 - rescale_zero_terminal_snr(b), 0)
+    assert float(ab[-1]) < 1e-6 and abs(float(ab[0]) - float(1 - b[0])) < 1e-6         # terminal SNR zero, first step untouched
+    with pytest.raises(ValueError, match="prediction_type"):
+        get_scheduler("dps")(operator=None, **base, prediction_type="flow")
+    with pytest.raises(NotImplementedError, match="thresholding"):
+        get_scheduler("dps")(operator=None, **base, clip_sample=False, thresholding=True)
