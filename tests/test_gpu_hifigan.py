@@ -102,3 +102,31 @@ def test_fp16_torch_oracle_shows_the_same_mask_flip_gap():
     assert lin["grad_hip"] < 1.5 * lin["grad_fp16_torch"] + 1e-2, lin
     assert real["grad_fp16_torch"] > lin["grad_fp16_torch"], out             # more kinks, more flips
     assert real["wav_hip"] < 1e-2 and real["wav_fp16_torch"] < 1e-2, real    # forward: rounding level on both
+
+
+def test_hifigan_layout_a_checkpoint_config_can_ask_for():
+    """Three upsamplers (4, 4, 2), two resblock kernel sizes with two dilations each, 40 mel bins, slope 0.2 (vocoder/config.json keys
+    upsample_rates / upsample_kernel_sizes / resblock_kernel_sizes / resblock_dilation_sizes / model_in_dim / leaky_relu_slope)."""
+    from diffmusic_amd.engine import HifiGanEngine
+    from oracle.models import HifiGan
+    cfg = dict(model_in_dim=40, upsample_initial_channel=64, upsample_rates=[4, 4, 2], upsample_kernel_sizes=[8, 8, 4],
+               resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2], [1, 3]], leaky_relu_slope=0.2)
+    eng = HifiGanEngine(cfg)
+    sd = eng.synth_state_dict(seed=4)
+    eng.load_state_dict(sd)
+    ref = HifiGan(**cfg)
+    ref.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(12)
+    B, T = 2, 48
+    mel = torch.randn(B, T, 40, generator=g).to(_adt())
+    dw = torch.randn(B, eng.out_len(T), generator=g)
+    wav = eng.forward(mel.cuda())
+    dmel = eng.backward(dw.cuda())
+    torch.cuda.synchronize()
+    x = mel.float().requires_grad_(True)
+    wref = ref(x)
+    (gref,) = torch.autograd.grad((wref * dw).sum(), x)
+    assert wav.shape == wref.shape == (B, 32 * T)
+    cos = torch.nn.functional.cosine_similarity(dmel.cpu().float().flatten(), gref.flatten(), dim=0).item()
+    print("rel err wav", _rel(wav.cpu(), wref), "grad", _rel(dmel.cpu(), gref), "cos", cos)
+    assert wref.abs().mean() > 0.02 and _rel(wav.cpu(), wref) < 3e-2 and cos > 0.97

@@ -32,6 +32,33 @@ def test_unet_fwd_vs_oracle(B, h, w, t):
     assert _rel(out.cpu(), oref) < 1e-2
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(SMALL, down_attn=[1, 1, 1, 0], up_attn=[0, 1, 1, 1]),                          # diffusers' default block order: attention at the first levels
+    dict(SMALL, block_out_channels=[32, 64, 128], down_attn=[1, 1, 0], up_attn=[0, 1, 1], layers_per_block=1, attention_heads=2),
+    dict(SMALL, down_attn=[0, 0, 0, 0], up_attn=[0, 0, 0, 0], class_embed_dim=0),       # no attention blocks, no class embedding (mid block only)
+])
+def test_unet_layouts_a_checkpoint_config_can_ask_for(cfg):
+    """`from_pretrained(<dir>)` configures the U-Net from the checkpoint's `down_block_types` / `up_block_types` / `layers_per_block` /
+    head count / `class_embed_type` (diffmusic_amd/checkpoint.py): layouts other than the benchmark's against the oracle."""
+    from diffmusic_amd.engine import UNetEngine
+    from oracle.models import UNetMusicLDM
+    eng = UNetEngine(cfg)
+    sd = eng.synth_state_dict(seed=13)
+    eng.load_state_dict(sd)
+    ref = UNetMusicLDM(**cfg)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn(B, 8, 32, 16, generator=g)               # (every attention level keeps a multiple of 4 tokens: the kernels' key granularity)
+    cls = torch.nn.functional.normalize(torch.randn(B, 512, generator=g), dim=-1) if cfg["class_embed_dim"] else None
+    out = eng.forward(x.cuda(), torch.full((B,), 301.0), cls.cuda() if cls is not None else None)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        oref = ref(x, 301, class_labels=cls)[0]
+    print("rel eps", _rel(out.cpu(), oref))
+    assert oref.std() > 0.05 and _rel(out.cpu(), oref) < 1e-2
+
+
 A2 = dict(SMALL, class_embed_dim=0, attn_cross_dims=[0, 48, 64])
 
 

@@ -103,3 +103,28 @@ def test_vae_is_invariant_to_batch_position_and_composition():
             assert torch.equal(mel[pos], base_mel[k]), f"mel of clip {k} at position {pos} of {order} differs from position {k}"
             assert torch.equal(dz[pos], base_dz[k]), f"input-gradient of clip {k} at position {pos} of {order} differs"
     assert float(base_mel.float().std()) > 0.05 and bool(torch.isfinite(base_dz).all())
+
+
+def test_vae_layout_a_checkpoint_config_can_ask_for():
+    """Two blocks, one layer per block, 4 latent channels, 16 groups (vae/config.json keys block_out_channels / layers_per_block /
+    latent_channels / norm_num_groups): forward and input-gradient against the oracle."""
+    from diffmusic_amd.engine import VaeDecoderEngine
+    from diffmusic_amd import _lib as L
+    from oracle.models import VaeDecoder
+    cfg = dict(latent_channels=4, out_channels=1, block_out_channels=[32, 64], layers_per_block=1, norm_num_groups=16, scaling_factor=0.5, eps=1e-6)
+    eng = VaeDecoderEngine(cfg)
+    sd = eng.synth_state_dict(seed=3)
+    eng.load_state_dict(sd)
+    ref = VaeDecoder(**cfg)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(2, 4, 12, 8, generator=g)
+    dmel = torch.randn(2, 24, 16, generator=g).to(L.act_dtype())
+    mel, mel32 = eng.decode_hip(z.cuda(), z_scale=2.0, want_f32=True)
+    dz = eng.backward(dmel.cuda(), z_scale=2.0)
+    torch.cuda.synchronize()
+    zr = z.clone().requires_grad_(True)
+    mref = ref.decode(2.0 * zr).sample[:, 0]
+    (gref,) = torch.autograd.grad((mref * dmel.float()).sum(), zr)
+    print("rel mel", _rel(mel32.cpu(), mref), "rel grad", _rel(dz.cpu(), gref))
+    assert mref.std() > 0.05 and _rel(mel32.cpu(), mref) < 1e-2 and _rel(dz.cpu(), gref) < 3e-2
