@@ -211,13 +211,17 @@ inline int attention_core(Ctx& cx, const act_t* q, const act_t* k, const act_t* 
   Arena& A = *cx.arena;
   const int dh = C / heads, Z = B * heads;
   const int Nkp = pad8(Nk);           // P / vT rows are padded to a multiple of 8 keys (zero columns)
-  if ((Nk & 3) || (dh & 7)) { dmx_set_error("attention needs Nk %% 4 == 0 and head_dim %% 8 == 0 (Nk=%d, dh=%d)", Nk, dh); return DMX_ERR_SHAPE; }
+  if (dh & 7) { dmx_set_error("attention needs head_dim %% 8 == 0 (dh=%d)", dh); return DMX_ERR_SHAPE; }
   const float scale = 1.0f / sqrtf((float)dh);
   const size_t mk = A.mark();
   // scores are written by the GEMM epilogue as fp16 straight into the P buffer (row pitch Nkp) and soft-maxed in place:
   // half the HBM traffic of an fp32 score matrix (the N = 1000 U-Net levels are write-bound on it)
   static const bool fused_ok = getenv("DMX_NO_FLASH") == nullptr;
-  if (!P_keep && fused_ok && dmx_flash_attn_ok(dh, C)) {
+  const bool flash = !P_keep && fused_ok && dmx_flash_attn_ok(dh, C);
+  // (the flash kernel masks its key tail per key: any Nk -- an 8 s clip's deepest U-Net level has 25 x 2 = 50 tokens; the materialised
+  //  path's softmax walks 4 keys per lane)
+  if (!flash && (Nk & 3)) { dmx_set_error("attention through materialised scores needs Nk %% 4 == 0 (Nk=%d)", Nk); return DMX_ERR_SHAPE; }
+  if (flash) {
     // forward-only callers (the U-Net): no score matrix at all -- flash_attn.hip walks the keys with an online softmax and takes
     // q, k, v as they come out of the projections (V is transposed inside the kernel on its way into LDS)
     CRUN(dmx_flash_attn_fwd(q, k, v, o, colbias, B, Nq, Nk, C, heads, scale, cx.st, ldq, ldk, ldv));

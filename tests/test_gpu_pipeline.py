@@ -184,3 +184,18 @@ def test_from_pretrained_directory_with_non_default_architecture(tmp_path):
                       show_progress=False).audios)
     assert outs[0].shape == (1, 6400) and bool((abs(outs[0]) <= 1.0).all()) and float(abs(outs[0]).max()) > 1e-4
     assert (outs[0] == outs[1]).all()
+
+
+def test_pipeline_runs_at_a_length_whose_deepest_level_has_an_odd_row_count():
+    """0.96 s -> latent 24 x 16 -> U-Net levels of 24, 12, 6, 3 rows: 3 x 2 = 6 tokens in the deepest attention (an 8 s clip has 25 x 2 = 50).
+    The attention kernels take any key count (they used to require a multiple of 4: 8 s clips failed)."""
+    from diffmusic_amd import inverse_problem as P
+    pipe = _build("musicldm", UNET, "dps", P.MusicInpaintingOperator(1, 15360, "box", 0.25, 0.5, 0.3, 0.1, 0.2, noiser=P.get_noiser("gaussian", 0.0)))
+    pipe.assume_uncond_equals_cond = True
+    g = torch.Generator().manual_seed(3)
+    L = 15360
+    y = pipe.scheduler.operator.forward((0.2 * torch.randn(1, L, generator=g)).cuda())
+    pe = torch.nn.functional.normalize(torch.randn(1, 512, generator=g), dim=-1)
+    out = pipe(prompt_embeds=pe, audio_length_in_s=0.96, num_inference_steps=3, generator=[torch.Generator().manual_seed(0)], measurement=y,
+               show_progress=False)
+    assert out.audios.shape == (1, L) and bool(torch.isfinite(torch.from_numpy(out.audios)).all()) and pipe.nan_restarts == 0

@@ -11,7 +11,7 @@ def _rel(a, b):
     return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-12)).item()
 
 
-@pytest.mark.parametrize("B,h,w,t", [(2, 26, 16, 981.0), (1, 30, 16, 1.0)])
+@pytest.mark.parametrize("B,h,w,t", [(2, 26, 16, 981.0), (1, 30, 16, 1.0), (2, 24, 16, 501.0)])     # (h = 24: 3 x 2 = 6 tokens at the deepest level)
 def test_unet_fwd_vs_oracle(B, h, w, t):
     from diffmusic_amd.engine import UNetEngine
     from oracle.models import UNetMusicLDM
