@@ -384,6 +384,33 @@ __device__ __forceinline__ void gn_parts_combine(const GnParts& sp, int b, int C
       if (q1 <= q0) continue;
       const int ns = gn_parts_nslots(R, b), slots = (R.P + R.tm - 1) / R.tm + 1;
       const float2* src = STAGED ? s_buf + soff[r] : reinterpret_cast<const float2*>(R.part) + (long long)b * slots * R.nq;
+      const int nq = q1 - q0;
+      if (!STAGED && nq <= 2) {
+        // straight from global memory (the big tensors, whose partial sums do not fit LDS): 8 slots x <= 2 quads of loads in flight per
+        // thread, then the same additions in the same order as the plain loop below (a thread of the 64000-pixel tensors walks 31 slots:
+        // one dependent round trip each cost the one-workgroup-per-image launch 23 us)
+        for (int j0 = slice; j0 < ns; j0 += 8 * nslice) {
+          float2 v[8][2];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * nslice;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) v[u][q] = (j < ns && q < nq) ? src[j * R.nq + q0 + q] : make_float2(0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * nslice;
+            if (j >= ns) break;
+            const int rows = gn_parts_rows(R, b, j);
+            if (rows <= 0) continue;
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) if (q < nq) { sv += v[u][q].x; qv += v[u][q].y; }
+            f(sv, qv, (float)rows * 4.f * (float)nq);
+          }
+        }
+        continue;
+      }
       for (int j = slice; j < ns; j += nslice) {
         const int rows = gn_parts_rows(R, b, j);
         if (rows <= 0) continue;
